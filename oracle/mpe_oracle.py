@@ -1,0 +1,488 @@
+"""CPU oracle for the multiagent-particle-envs hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-spec numpy restatement of the reference's algorithm for
+``MultiAgentEnv.step`` -> ``World.step`` -> scenario observation/reward/info
+(reference = /root/reference/multiagent-particle-envs, live ``multiagent/core.py``
+and ``multiagent/environment.py``; scenarios from ``build/lib/multiagent/scenarios``).
+It is pinned bit-exactly against golden vectors produced by the reference itself
+(``tests/golden/gen_golden.py`` -> ``tests/golden/*.npz``; see
+``tests/test_oracle_golden.py``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module, and only as the checker / reported CPU
+baseline.  The product (``marl_amd``) never imports it and has no CPU fallback.
+
+Two restatements live here:
+
+* ``SerialEnv``   one env, one Python object per entity, tiny (2,) float64 arrays,
+                  same evaluation order as the reference (this is the "serial numpy
+                  loop" timed as the CPU baseline).
+* ``BatchedOracle``  the same arithmetic, same per-element operation order,
+                  vectorised over a batch axis with SoA arrays ``pos[E,2,B]``,
+                  ``vel[A,2,B]`` (usable at 10^5..10^6 envs, float64 or float32).
+
+Plus ``philox4x32_10`` / ``reset_positions``: the restatement of this build's own
+device reset RNG (no reference counterpart: the reference draws from the global
+``np.random`` stream, simple_tag.py:47-54).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+SIMPLE_TAG = 0
+SIMPLE_SPREAD = 1
+
+
+# --------------------------------------------------------------------------------------
+# Scenario constants (what make_world() sets up)
+# --------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class ScenarioSpec:
+    kind: int
+    n_agents: int
+    n_landmarks: int
+    adversary: Sequence[bool]            # per agent
+    size: Sequence[float]                # per entity (agents then landmarks, core.py:109-111)
+    accel: Sequence[Optional[float]]     # per agent; None -> sensitivity 5.0 (environment.py:193-195)
+    max_speed: Sequence[Optional[float]]  # per agent; None -> no clamp (core.py:217)
+    collide: Sequence[bool]              # per entity
+    movable: Sequence[bool]              # per entity
+    u_noise: Sequence[Optional[float]]   # per agent (core.py:73,147)
+    mass: Sequence[float]                # per entity (core.py:47,51-53 -> 1.0)
+    agent_pos_range: float = 1.0         # reset: U(-r, r) (simple_tag.py:48, simple_spread.py:39)
+    landmark_pos_range: float = 0.9      # simple_tag.py:53 (0.9), simple_spread.py:43 (1.0)
+    dim_c: int = 2
+    dt: float = 0.1                      # core.py:100
+    damping: float = 0.25                # core.py:102
+    contact_force: float = 1e2           # core.py:104
+    contact_margin: float = 1e-3         # core.py:105
+
+    @property
+    def n_entities(self):
+        return self.n_agents + self.n_landmarks
+
+    def obs_dim(self, i):
+        A, L = self.n_agents, self.n_landmarks
+        if self.kind == SIMPLE_TAG:
+            n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
+            return 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others
+        return 4 + 2 * L + 2 * (A - 1) + self.dim_c * (A - 1)
+
+    @property
+    def obs_dims(self):
+        return [self.obs_dim(i) for i in range(self.n_agents)]
+
+    @property
+    def info_width(self):
+        return 1 if self.kind == SIMPLE_TAG else 4
+
+
+def simple_tag_spec(n_adv=3, n_good=1, n_landmarks=2, u_noise=None):
+    """simple_tag.py:7-36 (per-role constants); scaled variants keep the same roles."""
+    A = n_adv + n_good
+    adv = [i < n_adv for i in range(A)]
+    return ScenarioSpec(
+        kind=SIMPLE_TAG, n_agents=A, n_landmarks=n_landmarks, adversary=adv,
+        size=[0.075 if a else 0.05 for a in adv] + [0.2] * n_landmarks,
+        accel=[3.0 if a else 4.0 for a in adv],
+        max_speed=[1.0 if a else 1.3 for a in adv],
+        collide=[True] * (A + n_landmarks),
+        movable=[True] * A + [False] * n_landmarks,
+        u_noise=[u_noise] * A, mass=[1.0] * (A + n_landmarks),
+        agent_pos_range=1.0, landmark_pos_range=0.9)
+
+
+def simple_spread_spec(n_agents=3, n_landmarks=3, u_noise=None):
+    """simple_spread.py:7-28."""
+    A = n_agents
+    return ScenarioSpec(
+        kind=SIMPLE_SPREAD, n_agents=A, n_landmarks=n_landmarks, adversary=[False] * A,
+        size=[0.15] * A + [0.05] * n_landmarks,
+        accel=[None] * A, max_speed=[None] * A,
+        collide=[True] * A + [False] * n_landmarks,
+        movable=[True] * A + [False] * n_landmarks,
+        u_noise=[u_noise] * A, mass=[1.0] * (A + n_landmarks),
+        agent_pos_range=1.0, landmark_pos_range=1.0)
+
+
+# --------------------------------------------------------------------------------------
+# Serial restatement: one Python object per entity (the CPU baseline shape)
+# --------------------------------------------------------------------------------------
+class _Body:
+    __slots__ = ('is_agent', 'adversary', 'size', 'accel', 'max_speed', 'collide', 'movable',
+                 'u_noise', 'mass', 'pos', 'vel', 'comm', 'u')
+
+
+class SerialEnv:
+    """One environment instance; mirrors environment.py:92-129 + core.py:124-249."""
+
+    def __init__(self, spec: ScenarioSpec, benchmark=True):
+        self.spec = spec
+        self.benchmark = benchmark
+        self.bodies: List[_Body] = []
+        for e in range(spec.n_entities):
+            b = _Body()
+            b.is_agent = e < spec.n_agents
+            b.adversary = bool(spec.adversary[e]) if b.is_agent else False
+            b.size = spec.size[e]
+            b.accel = spec.accel[e] if b.is_agent else None
+            b.max_speed = spec.max_speed[e] if b.is_agent else None
+            b.collide = bool(spec.collide[e])
+            b.movable = bool(spec.movable[e])
+            b.u_noise = spec.u_noise[e] if b.is_agent else None
+            b.mass = spec.mass[e]
+            b.pos = np.zeros(2)
+            b.vel = np.zeros(2)
+            b.comm = np.zeros(spec.dim_c)
+            b.u = np.zeros(2)
+            self.bodies.append(b)
+        self.agents = self.bodies[:spec.n_agents]
+        self.landmarks = self.bodies[spec.n_agents:]
+        self.n = spec.n_agents
+
+    # -- state helpers ----------------------------------------------------------------
+    def set_state(self, pos, vel):
+        for e, b in enumerate(self.bodies):
+            b.pos = np.array(pos[e], dtype=np.float64)
+        for i, a in enumerate(self.agents):
+            a.vel = np.array(vel[i], dtype=np.float64)
+
+    def get_state(self):
+        return (np.stack([b.pos for b in self.bodies]), np.stack([a.vel for a in self.agents]))
+
+    # -- reset: simple_tag.py:39-54 / simple_spread.py:30-44 (global np.random stream) --
+    def reset(self):
+        s = self.spec
+        for a in self.agents:
+            a.pos = np.random.uniform(-s.agent_pos_range, +s.agent_pos_range, 2)
+            a.vel = np.zeros(2)
+            a.comm = np.zeros(s.dim_c)
+        for lm in self.landmarks:
+            lm.pos = np.random.uniform(-s.landmark_pos_range, +s.landmark_pos_range, 2)
+            lm.vel = np.zeros(2)
+        return [self.observation(i) for i in range(self.n)]
+
+    # -- environment.py:157-208 (Discrete(5) soft one-hot path) --------------------------
+    def _decode_action(self, agent, action):
+        u = np.zeros(2)
+        u[0] += action[1] - action[2]
+        u[1] += action[3] - action[4]
+        u *= 5.0 if agent.accel is None else agent.accel
+        agent.u = u
+
+    # -- core.py:124-140 ----------------------------------------------------------------
+    def world_step(self):
+        s = self.spec
+        force = [None] * len(self.bodies)
+        # core.py:143-149
+        for i, a in enumerate(self.agents):
+            if a.movable:
+                nz = np.random.randn(2) * a.u_noise if a.u_noise else 0.0
+                force[i] = a.u + nz
+        # core.py:153-194 is a no-op for forced_id < 0
+        # core.py:197-208 (one-sided: only the lower-indexed entity of a pair is pushed)
+        for ia, ea in enumerate(self.bodies):
+            for ib in range(ia + 1, len(self.bodies)):
+                eb = self.bodies[ib]
+                if not (ea.collide and eb.collide):
+                    continue
+                d = ea.pos - eb.pos
+                dist = np.sqrt(np.sum(np.square(d)))
+                dmin = ea.size + eb.size
+                k = s.contact_margin
+                pen = np.logaddexp(0, -(dist - dmin) / k) * k
+                f = s.contact_force * d / dist * pen
+                if ea.movable:
+                    if force[ia] is None:
+                        force[ia] = 0.0
+                    force[ia] = f + force[ia]
+                if eb.movable and force[ib] is None:
+                    force[ib] = 0.0
+        # core.py:211-222
+        for i, e in enumerate(self.bodies):
+            if not e.movable:
+                continue
+            e.vel = e.vel * (1 - s.damping)
+            if force[i] is not None:
+                e.vel = e.vel + (force[i] / e.mass) * s.dt
+            if e.max_speed is not None:
+                speed = np.sqrt(np.square(e.vel[0]) + np.square(e.vel[1]))
+                if speed > e.max_speed:
+                    e.vel = e.vel / np.sqrt(np.square(e.vel[0]) + np.square(e.vel[1])) * e.max_speed
+            e.pos = e.pos + e.vel * s.dt
+        # core.py:224-230 (all agents silent)
+        for a in self.agents:
+            a.comm = np.zeros(s.dim_c)
+
+    # -- scenario gathers -----------------------------------------------------------------
+    @staticmethod
+    def _touching(p, q):
+        d = p.pos - q.pos
+        return bool(np.sqrt(np.sum(np.square(d))) < p.size + q.size)
+
+    def observation(self, i):
+        me = self.agents[i]
+        rel_lm = [lm.pos - me.pos for lm in self.landmarks]
+        rel_ag, tail = [], []
+        for j, other in enumerate(self.agents):
+            if other is me:
+                continue
+            rel_ag.append(other.pos - me.pos)
+            if self.spec.kind == SIMPLE_TAG:
+                if not other.adversary:
+                    tail.append(other.vel)        # simple_tag.py:145-146
+            else:
+                tail.append(other.comm)           # simple_spread.py:97,99
+        return np.concatenate([me.vel, me.pos] + rel_lm + rel_ag + tail)
+
+    def reward(self, i):
+        me = self.agents[i]
+        if self.spec.kind == SIMPLE_TAG:
+            advs = [a for a in self.agents if a.adversary]
+            goods = [a for a in self.agents if not a.adversary]
+            r = 0
+            if me.adversary:                       # simple_tag.py:115-129
+                if me.collide:
+                    for g in goods:
+                        for a in advs:
+                            if self._touching(g, a):
+                                r += 10
+                return r
+            if me.collide:                         # simple_tag.py:89-113
+                for a in advs:
+                    if self._touching(a, me):
+                        r -= 10
+            for p in range(2):
+                x = abs(me.pos[p])
+                if x < 0.9:
+                    pen = 0
+                elif x < 1.0:
+                    pen = (x - 0.9) * 10
+                else:
+                    pen = min(np.exp(2 * x - 2), 10)
+                r -= pen
+            return r
+        r = 0                                      # simple_spread.py:71-81
+        for lm in self.landmarks:
+            r -= min(np.sqrt(np.sum(np.square(a.pos - lm.pos))) for a in self.agents)
+        if me.collide:
+            for a in self.agents:
+                if self._touching(a, me):
+                    r -= 1
+        return r
+
+    def info(self, i):
+        me = self.agents[i]
+        if self.spec.kind == SIMPLE_TAG:           # simple_tag.py:57-66
+            if not me.adversary:
+                return 0
+            return sum(1 for g in self.agents if not g.adversary and self._touching(g, me))
+        r, coll, occ, md = 0, 0, 0, 0              # simple_spread.py:46-62
+        for lm in self.landmarks:
+            m = min(np.sqrt(np.sum(np.square(a.pos - lm.pos))) for a in self.agents)
+            md += m
+            r -= m
+            if m < 0.1:
+                occ += 1
+        if me.collide:
+            for a in self.agents:
+                if self._touching(a, me):
+                    r -= 1
+                    coll += 1
+        return (r, coll, md, occ)
+
+    # -- environment.py:92-117 ---------------------------------------------------------------
+    def step(self, action_n):
+        for i, a in enumerate(self.agents):
+            self._decode_action(a, action_n[i])
+        self.world_step()
+        obs_n, rew_n, done_n, info_n = [], [], [], {'n': []}
+        for i in range(self.n):
+            obs_n.append(self.observation(i))
+            rew_n.append(self.reward(i))
+            done_n.append(False)
+            info_n['n'].append(self.info(i) if self.benchmark else {})
+        return obs_n, rew_n, done_n, info_n
+
+
+# --------------------------------------------------------------------------------------
+# Batched restatement (SoA, vectorised over envs, same per-element operation order)
+# --------------------------------------------------------------------------------------
+class BatchedOracle:
+    """pos[E,2,B], vel[A,2,B]; act[A,5,B]; noise[A,2,B] standard normals (or None)."""
+
+    def __init__(self, spec: ScenarioSpec, dtype=np.float64):
+        self.spec = spec
+        self.dt = np.dtype(dtype).type
+
+    def world_step(self, pos, vel, act, noise=None):
+        s, T = self.spec, self.dt
+        A, E = s.n_agents, s.n_entities
+        pos = np.array(pos, dtype=T)
+        vel = np.array(vel, dtype=T)
+        act = np.asarray(act, dtype=T)
+        force = [None] * E
+        with np.errstate(all='ignore'):
+            for i in range(A):
+                sens = T(5.0 if s.accel[i] is None else s.accel[i])
+                u = np.stack([(act[i, 1] - act[i, 2]) * sens, (act[i, 3] - act[i, 4]) * sens])
+                if s.movable[i]:
+                    if s.u_noise[i]:
+                        u = u + np.asarray(noise[i], dtype=T) * T(s.u_noise[i])
+                    force[i] = u
+            k = T(s.contact_margin)
+            cf = T(s.contact_force)
+            for a in range(E):
+                if not (s.movable[a] and s.collide[a]):
+                    continue
+                for b in range(a + 1, E):
+                    if not s.collide[b]:
+                        continue
+                    d = pos[a] - pos[b]
+                    dist = np.sqrt(np.square(d[0]) + np.square(d[1]))
+                    dmin = T(s.size[a]) + T(s.size[b])
+                    pen = np.logaddexp(T(0), -(dist - dmin) / k) * k
+                    f = cf * d / dist * pen
+                    force[a] = f + (force[a] if force[a] is not None else T(0))
+            for i in range(E):
+                if not s.movable[i]:
+                    continue
+                v = vel[i] * T(1 - s.damping)
+                if force[i] is not None:
+                    v = v + (force[i] / T(s.mass[i])) * T(s.dt)
+                if i < A and s.max_speed[i] is not None:
+                    ms = T(s.max_speed[i])
+                    speed = np.sqrt(np.square(v[0]) + np.square(v[1]))
+                    clamped = v / speed * ms
+                    v = np.where(speed > ms, clamped, v)
+                vel[i] = v
+                pos[i] = pos[i] + v * T(s.dt)
+        return pos, vel
+
+    def _dist(self, pos, i, j):
+        d = pos[i] - pos[j]
+        return np.sqrt(np.square(d[0]) + np.square(d[1]))
+
+    def observe(self, pos, vel, want_info=True):
+        """Returns obs (list of [dim_i, B]), rew [A,B], info [A,W,B]."""
+        s, T = self.spec, self.dt
+        A, L, E = s.n_agents, s.n_landmarks, s.n_entities
+        B = pos.shape[-1]
+        pos = np.asarray(pos, dtype=T)
+        vel = np.asarray(vel, dtype=T)
+        obs = []
+        for i in range(A):
+            rows = [vel[i], pos[i]]
+            rows += [pos[A + l] - pos[i] for l in range(L)]
+            rows += [pos[j] - pos[i] for j in range(A) if j != i]
+            if s.kind == SIMPLE_TAG:
+                rows += [vel[j] for j in range(A) if j != i and not s.adversary[j]]
+            else:
+                rows += [np.zeros((s.dim_c, B), T) for j in range(A) if j != i]
+            obs.append(np.concatenate(rows, axis=0))
+        rew = np.zeros((A, B), T)
+        info = np.zeros((A, s.info_width, B), T)
+        with np.errstate(all='ignore'):
+            if s.kind == SIMPLE_TAG:
+                advs = [i for i in range(A) if s.adversary[i]]
+                goods = [i for i in range(A) if not s.adversary[i]]
+                total = np.zeros(B, T)
+                for g in goods:
+                    n_g = np.zeros(B, T)
+                    for a in advs:
+                        hit = self._dist(pos, g, a) < T(s.size[g] + s.size[a])
+                        n_g = n_g + hit
+                        info[a, 0] += hit
+                    total = total + n_g
+                    r = -T(10) * n_g if s.collide[g] else np.zeros(B, T)
+                    for p in range(2):
+                        x = np.abs(pos[g, p])
+                        bnd = np.where(x < T(0.9), T(0),
+                                       np.where(x < T(1.0), (x - T(0.9)) * T(10),
+                                                np.minimum(np.exp(T(2) * x - T(2)), T(10))))
+                        r = r - bnd
+                    rew[g] = r
+                for a in advs:
+                    rew[a] = T(10) * total if s.collide[a] else 0
+            else:
+                r0 = np.zeros(B, T)
+                md = np.zeros(B, T)
+                occ = np.zeros(B, T)
+                for l in range(L):
+                    m = self._dist(pos, 0, A + l)
+                    for a in range(1, A):
+                        m = np.minimum(m, self._dist(pos, a, A + l))
+                    md = md + m
+                    r0 = r0 - m
+                    occ = occ + (m < T(0.1))
+                for i in range(A):
+                    r = r0.copy()
+                    c = np.zeros(B, T)
+                    if s.collide[i]:
+                        for a in range(A):
+                            hit = self._dist(pos, a, i) < T(s.size[a] + s.size[i])
+                            r = r - hit
+                            c = c + hit
+                    rew[i] = r
+                    info[i, 0], info[i, 1], info[i, 2], info[i, 3] = r, c, md, occ
+        return obs, rew, (info if want_info else None)
+
+    def env_step(self, pos, vel, act, noise=None):
+        pos, vel = self.world_step(pos, vel, act, noise)
+        obs, rew, info = self.observe(pos, vel)
+        return pos, vel, obs, rew, info
+
+
+# --------------------------------------------------------------------------------------
+# Device reset RNG restatement (this build's own spec; no reference counterpart)
+# --------------------------------------------------------------------------------------
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11).  ctr: 4 arrays of uint32, key: 2 arrays of uint32."""
+    c = [np.asarray(x, dtype=np.uint32).copy() for x in ctr]
+    k = [np.asarray(x, dtype=np.uint32).copy() for x in key]
+    with np.errstate(over='ignore'):
+        for r in range(10):
+            p0 = _M0 * c[0].astype(np.uint64)
+            p1 = _M1 * c[2].astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & _MASK).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & _MASK).astype(np.uint32)
+            c = [hi1 ^ c[1] ^ k[0], lo1, hi0 ^ c[3] ^ k[1], lo0]
+            k = [(k[0] + _W0).astype(np.uint32), (k[1] + _W1).astype(np.uint32)]
+    return c
+
+
+def _u01(hi, lo):
+    """53-bit uniform in [0,1) from two uint32 words."""
+    a = (hi >> np.uint32(5)).astype(np.float64)
+    b = (lo >> np.uint32(6)).astype(np.float64)
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0)
+
+
+def reset_positions(spec: ScenarioSpec, seed: int, episode, env_ids, dtype=np.float64):
+    """pos[E,2,B] for envs ``env_ids`` (global ids) at per-env episode counter ``episode``.
+
+    counter = (env_lo, env_hi, episode, entity), key = (seed_lo, seed_hi);
+    x <- words (0,1), y <- words (2,3);  p = -r + (2r) * u  (np.random.uniform's formula).
+    """
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    B = env_ids.shape[0]
+    episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), (B,))
+    lo = (env_ids & _MASK).astype(np.uint32)
+    hi = (env_ids >> np.uint64(32)).astype(np.uint32)
+    k0 = np.full(B, seed & 0xFFFFFFFF, np.uint32)
+    k1 = np.full(B, (seed >> 32) & 0xFFFFFFFF, np.uint32)
+    pos = np.zeros((spec.n_entities, 2, B), dtype)
+    for e in range(spec.n_entities):
+        r = spec.agent_pos_range if e < spec.n_agents else spec.landmark_pos_range
+        w = philox4x32_10([lo, hi, episode, np.full(B, e, np.uint32)], [k0, k1])
+        pos[e, 0] = (-r + (2.0 * r) * _u01(w[0], w[1])).astype(dtype)
+        pos[e, 1] = (-r + (2.0 * r) * _u01(w[2], w[3])).astype(dtype)
+    return pos

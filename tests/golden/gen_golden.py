@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (build container only; never runs on the GPU box).
+
+Imports the *reference* implementation from /root/reference (read-only), rolls
+out episodes and dumps inputs + expected outputs as small .npz fixtures next to
+this file.  Nothing of the reference is copied: this script only contains the
+harness scaffolding from SURVEY.md Appendix A (an in-memory ``gym`` stand-in so
+``import multiagent`` works, and the ``forced_id/force_id = -1`` attributes the
+fork's ``World.step`` needs, reference core.py:157-159).
+
+Cases:
+  G1  simple_tag      64 seeds x 25 steps, benchmark=True
+  G2  simple_spread   64 seeds x 25 steps, benchmark=True (info 4-tuple)
+  G3  scaled tag 48 adv / 16 good / 32 landmarks, 2 seeds x 12 steps
+  G4  simple_tag with u_noise = 0.3 (core.py:147), 16 seeds x 25 steps
+  G5  dense starts U(-0.3, 0.3): collisions / max_speed clamp / +-10 rewards fire
+      (tag and spread)
+  G6  out-of-bounds starts: all four branches of simple_tag bound()
+  KAT known-answer cases 1, 2, 4 of SURVEY.md section 8c
+
+Run:  python tests/golden/gen_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference/multiagent-particle-envs'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_gym_stub():
+    gym = types.ModuleType('gym')
+    gym.Env = type('Env', (), {})
+    gym.Space = type('Space', (), {})
+    sp = types.ModuleType('gym.spaces')
+
+    class Discrete(gym.Space):
+        def __init__(self, n):
+            self.n = n
+
+    class Box(gym.Space):
+        def __init__(self, low, high, shape=None, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class Tuple(gym.Space):
+        def __init__(self, spaces):
+            self.spaces = spaces
+
+    sp.Discrete, sp.Box, sp.Tuple = Discrete, Box, Tuple
+    sp.prng = types.SimpleNamespace(np_random=np.random)
+    envs = types.ModuleType('gym.envs')
+    reg = types.ModuleType('gym.envs.registration')
+    reg.register = lambda **kw: None
+    reg.EnvSpec = object
+    gym.spaces, gym.envs, envs.registration = sp, envs, reg
+    sys.modules.update({'gym': gym, 'gym.spaces': sp, 'gym.envs': envs,
+                        'gym.envs.registration': reg})
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_install_gym_stub()
+sys.path.insert(0, REF)
+from multiagent.environment import MultiAgentEnv  # noqa: E402  (reference)
+from multiagent.core import World, Agent, Landmark  # noqa: E402  (reference)
+
+TAG = _load(REF + '/build/lib/multiagent/scenarios/simple_tag.py', 'ref_simple_tag')
+SPREAD = _load(REF + '/build/lib/multiagent/scenarios/simple_spread.py', 'ref_simple_spread')
+
+
+def _shim(world):
+    for a in world.agents:
+        a.forced_id = -1
+        a.force_id = -1
+        a.advsuperleader = False
+
+
+def build_env(kind, seed, scaled=None, u_noise=None):
+    """kind in {'simple_tag', 'simple_spread'}; scaled=(n_adv, n_good, n_landmarks)."""
+    np.random.seed(seed)
+    if kind == 'simple_tag':
+        S = TAG.Scenario()
+        if scaled is None:
+            world = S.make_world()
+        else:
+            n_adv, n_good, n_lm = scaled
+            world = World()
+            world.dim_c = 2
+            world.agents = [Agent() for _ in range(n_adv + n_good)]
+            for i, ag in enumerate(world.agents):
+                ag.name = 'agent %d' % i
+                ag.collide = True
+                ag.silent = True
+                ag.adversary = i < n_adv
+                ag.size = 0.075 if ag.adversary else 0.05
+                ag.accel = 3.0 if ag.adversary else 4.0
+                ag.max_speed = 1.0 if ag.adversary else 1.3
+            world.landmarks = [Landmark() for _ in range(n_lm)]
+            for i, lm in enumerate(world.landmarks):
+                lm.name = 'landmark %d' % i
+                lm.collide = True
+                lm.movable = False
+                lm.size = 0.2
+                lm.boundary = False
+            S.reset_world(world)
+    else:
+        S = SPREAD.Scenario()
+        world = S.make_world()
+    _shim(world)
+    if u_noise is not None:
+        for a in world.agents:
+            a.u_noise = u_noise
+    env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data)
+    return env, world
+
+
+def _state(world):
+    pos = np.stack([e.state.p_pos for e in world.entities]).astype(np.float64)
+    vel = np.stack([a.state.p_vel for a in world.agents]).astype(np.float64)
+    return pos, vel
+
+
+def _info_row(x):
+    return np.atleast_1d(np.asarray(x, dtype=np.float64))
+
+
+def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'):
+    """Returns dict of stacked arrays over seeds."""
+    keys = ('pos0', 'vel0', 'obs0', 'act', 'noise', 'pos', 'vel', 'obs', 'rew', 'info')
+    out = {k: [] for k in keys}
+    for seed in seeds:
+        env, world = build_env(kind, seed, scaled, u_noise)
+        A = len(world.agents)
+        obs0 = env.reset()
+        if init is not None:
+            init(world, np.random.RandomState(10_000 + seed))
+            obs0 = [env._get_obs(a) for a in env.agents]
+        pos0, vel0 = _state(world)
+        arng = np.random.RandomState(20_000 + seed)
+        ep = {k: [] for k in ('act', 'noise', 'pos', 'vel', 'obs', 'rew', 'info')}
+        for t in range(T):
+            if actions == 'rand':
+                act = arng.rand(A, 5)
+            elif actions == 'softmax':
+                logits = arng.randn(A, 5)
+                e = np.exp(logits - logits.max(axis=1, keepdims=True))
+                act = e / e.sum(axis=1, keepdims=True)
+            else:
+                act = np.zeros((A, 5))
+            s_t = 30_000 + 1000 * seed + t
+            np.random.seed(s_t)
+            noise = np.random.RandomState(s_t).randn(A, 2)
+            obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in range(A)])
+            assert not any(done_n)
+            pos, vel = _state(world)
+            ep['act'].append(act)
+            ep['noise'].append(noise)
+            ep['pos'].append(pos.copy())
+            ep['vel'].append(vel.copy())
+            ep['obs'].append(np.concatenate(obs_n))
+            ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
+            ep['info'].append(np.stack([_info_row(x) for x in info_n['n']]))
+        out['pos0'].append(pos0)
+        out['vel0'].append(vel0)
+        out['obs0'].append(np.concatenate(obs0))
+        for k in ep:
+            out[k].append(np.stack(ep[k]))
+    res = {k: np.stack(v) for k, v in out.items()}
+    res['seeds'] = np.asarray(list(seeds))
+    res['u_noise'] = np.float64(0.0 if u_noise is None else u_noise)
+    if u_noise is None:
+        res.pop('noise')
+    return res
+
+
+def dense_init(world, rng):
+    for e in world.entities:
+        e.state.p_pos = rng.uniform(-0.3, 0.3, 2)
+    for a in world.agents:
+        a.state.p_vel = rng.uniform(-0.5, 0.5, 2)
+
+
+def oob_init(world, rng):
+    mags = [0.85, 0.95, 1.5, 2.5]
+    for a in world.agents:
+        sx, sy = rng.choice([-1.0, 1.0], 2)
+        mx, my = rng.choice(mags, 2)
+        a.state.p_pos = np.array([sx * mx, sy * my]) + rng.uniform(-0.02, 0.02, 2)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('%-28s %8.1f KiB' % (name, os.path.getsize(path) / 1024))
+
+
+def kat_cases():
+    # KAT-1: one-sided contact (core.py:203-207)
+    env, world = build_env('simple_tag', 0)
+    env.reset()
+    far = [(5.0, 5.0), (-5.0, 5.0), (5.0, -5.0), (-5.0, -5.0)]
+    for i, e in enumerate(world.entities):
+        e.state.p_pos = np.array(far[i % 4]) * (1 + i)
+    world.agents[0].state.p_pos = np.array([0.0, 0.0])
+    world.agents[1].state.p_pos = np.array([0.1, 0.0])
+    pos0, vel0 = _state(world)
+    z = [np.zeros(5) for _ in world.agents]
+    obs_n, rew_n, _, info_n = env.step(z)
+    pos1, vel1 = _state(world)
+    save('kat1_one_sided', pos0=pos0, vel0=vel0, pos=pos1, vel=vel1,
+         obs=np.concatenate(obs_n), rew=np.asarray(rew_n, float),
+         info=np.stack([_info_row(x) for x in info_n['n']]))
+    # KAT-2: spread self-collision term (simple_spread.py:78-80)
+    env, world = build_env('simple_spread', 0)
+    env.reset()
+    for i in range(3):
+        world.landmarks[i].state.p_pos = np.array([float(i), 0.0])
+        world.agents[i].state.p_pos = np.array([float(i), 0.0])
+    pos0, vel0 = _state(world)
+    rew = np.array([env._get_reward(a) for a in env.agents], float)
+    info = np.stack([_info_row(env._get_info(a)) for a in env.agents])
+    save('kat2_spread_self', pos0=pos0, vel0=vel0, rew=rew, info=info)
+    # KAT-4: far-apart entities, zero action: pos bitwise unchanged, tiny vel
+    env, world = build_env('simple_tag', 0)
+    env.reset()
+    for i, e in enumerate(world.entities):
+        e.state.p_pos = np.array([-0.9 + 0.6 * (i % 3), -0.5 + 1.0 * (i // 3)])
+    pos0, vel0 = _state(world)
+    env.step([np.zeros(5) for _ in world.agents])
+    pos1, vel1 = _state(world)
+    save('kat4_far_zero', pos0=pos0, vel0=vel0, pos=pos1, vel=vel1)
+
+
+def main():
+    save('g1_simple_tag', **rollout('simple_tag', range(64), 25))
+    save('g2_simple_spread', **rollout('simple_spread', range(64), 25))
+    save('g3_scaled_tag', **rollout('simple_tag', range(2), 12, scaled=(48, 16, 32),
+                                    init=None, actions='softmax'))
+    save('g3d_scaled_tag_dense', **rollout('simple_tag', range(1), 6, scaled=(48, 16, 32),
+                                           init=dense_init, actions='softmax'))
+    save('g4_simple_tag_unoise', **rollout('simple_tag', range(16), 25, u_noise=0.3))
+    save('g5_simple_tag_dense', **rollout('simple_tag', range(32), 25, init=dense_init,
+                                          actions='softmax'))
+    save('g5_simple_spread_dense', **rollout('simple_spread', range(32), 25, init=dense_init,
+                                             actions='softmax'))
+    save('g6_simple_tag_oob', **rollout('simple_tag', range(24), 10, init=oob_init,
+                                        actions='rand'))
+    kat_cases()
+
+
+if __name__ == '__main__':
+    main()

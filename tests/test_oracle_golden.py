@@ -1,0 +1,189 @@
+"""Pin the CPU oracle (oracle/mpe_oracle.py) against golden vectors produced by the reference
+itself (tests/golden/gen_golden.py).  Bit-exact: the oracle repeats the reference's float64
+operations in the reference's order."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mpe_oracle as O
+
+CASES = [
+    ('g1_simple_tag', lambda: O.simple_tag_spec()),
+    ('g2_simple_spread', lambda: O.simple_spread_spec()),
+    ('g3_scaled_tag', lambda: O.simple_tag_spec(48, 16, 32)),
+    ('g3d_scaled_tag_dense', lambda: O.simple_tag_spec(48, 16, 32)),
+    ('g4_simple_tag_unoise', lambda: O.simple_tag_spec(u_noise=0.3)),
+    ('g5_simple_tag_dense', lambda: O.simple_tag_spec()),
+    ('g5_simple_spread_dense', lambda: O.simple_spread_spec()),
+    ('g6_simple_tag_oob', lambda: O.simple_tag_spec()),
+]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+class _FixedNoise:
+    """Feeds recorded standard normals to SerialEnv.world_step in the reference's draw order
+    (core.py:147: one randn(2) per agent, agents ascending)."""
+
+    def __init__(self, noise):
+        self.noise = noise
+        self.i = 0
+
+    def __call__(self, n):
+        assert n == 2
+        row = self.noise[self.i]
+        self.i += 1
+        return row
+
+
+@pytest.mark.parametrize('name,mk', CASES)
+def test_serial_oracle_bit_exact(golden_dir, name, mk, monkeypatch):
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    n_serial = min(S, 16) if spec.n_entities < 20 else 1      # scaled config: 1 seed is ~2 s
+    n_steps = T if spec.n_entities < 20 else min(T, 3)
+    for s in range(n_serial):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        assert np.array_equal(np.concatenate([env.observation(i) for i in range(env.n)]), g['obs0'][s])
+        for t in range(n_steps):
+            if 'noise' in g.files:
+                monkeypatch.setattr(np.random, 'randn', _FixedNoise(g['noise'][s, t]))
+            obs_n, rew_n, done_n, info_n = env.step(list(g['act'][s, t]))
+            pos, vel = env.get_state()
+            assert np.array_equal(pos, g['pos'][s, t]), (name, s, t)
+            assert np.array_equal(vel, g['vel'][s, t]), (name, s, t)
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
+            assert np.array_equal(np.asarray(rew_n, float), g['rew'][s, t]), (name, s, t)
+            info = np.stack([np.atleast_1d(np.asarray(x, float)) for x in info_n['n']])
+            assert np.array_equal(info, g['info'][s, t]), (name, s, t)
+            assert done_n == [False] * env.n
+
+
+@pytest.mark.parametrize('name,mk', CASES)
+def test_batched_oracle_bit_exact(golden_dir, name, mk):
+    """All seeds of a case as one batch; free-running trajectory from (pos0, vel0)."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    bo = O.BatchedOracle(spec, np.float64)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))   # [E,2,S]
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    obs, _, _ = bo.observe(pos, vel)
+    assert np.array_equal(np.concatenate(obs, 0), g['obs0'].T)
+    for t in range(T):
+        act = np.moveaxis(g['act'][:, t], 0, -1)                 # [A,5,S]
+        noise = np.moveaxis(g['noise'][:, t], 0, -1) if 'noise' in g.files else None
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, noise)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+        assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1)), (name, t)
+
+
+def test_golden_cases_exercise_the_branches(golden_dir):
+    """The dense / out-of-bounds fixtures really hit collisions, the clamp and all bound() arms."""
+    g = _load(golden_dir, 'g5_simple_tag_dense')
+    assert (g['rew'][:, :, 0] >= 10).any() and (g['rew'][:, :, 3] <= -10).any()
+    assert (g['info'][:, :, :3] > 0).any()
+    speed = np.sqrt((g['vel'] ** 2).sum(-1))
+    assert np.isclose(speed[:, :, :3], 1.0, atol=1e-12).any()        # adversary clamp fired
+    g = _load(golden_dir, 'g6_simple_tag_oob')
+    x = np.abs(g['pos'][:, :, 3])                                   # the good agent
+    assert (x < 0.9).any() and ((x >= 0.9) & (x < 1.0)).any()
+    assert ((x >= 1.0) & (x < 2.15)).any() and (x > 2.16).any()
+    g = _load(golden_dir, 'g5_simple_spread_dense')
+    assert (g['info'][:, :, :, 1] > 1).any() and (g['info'][:, :, :, 3] > 0).any()
+
+
+def test_kat1_one_sided_contact(golden_dir):
+    """SURVEY KAT-1: only the lower-indexed entity of a pair is pushed (core.py:203-207)."""
+    g = _load(golden_dir, 'kat1_one_sided')
+    spec = O.simple_tag_spec()
+    env = O.SerialEnv(spec)
+    env.set_state(g['pos0'], g['vel0'])
+    env.step([np.zeros(5)] * 4)
+    pos, vel = env.get_state()
+    assert np.array_equal(pos, g['pos']) and np.array_equal(vel, g['vel'])
+    np.testing.assert_allclose(vel[0], [-0.5, 0.0], atol=1e-12)
+    np.testing.assert_allclose(pos[0], [-0.05, 0.0], atol=1e-12)
+    assert np.all(np.abs(vel[1]) < 1e-100)                         # agent 1 receives nothing
+    bo = O.BatchedOracle(spec)
+    p, v = bo.world_step(g['pos0'][..., None], g['vel0'][..., None], np.zeros((4, 5, 1)))
+    assert np.array_equal(p[..., 0], g['pos']) and np.array_equal(v[..., 0], g['vel'])
+
+
+def test_kat2_spread_self_collision(golden_dir):
+    """SURVEY KAT-2: every agent's reward includes -1 for 'colliding' with itself."""
+    g = _load(golden_dir, 'kat2_spread_self')
+    spec = O.simple_spread_spec()
+    env = O.SerialEnv(spec)
+    env.set_state(g['pos0'], g['vel0'])
+    rew = np.array([env.reward(i) for i in range(3)], float)
+    assert np.array_equal(rew, g['rew']) and np.array_equal(rew, [-1.0, -1.0, -1.0])
+    info = np.stack([np.asarray(env.info(i), float) for i in range(3)])
+    assert np.array_equal(info, g['info'])
+    _, r, inf = O.BatchedOracle(spec).observe(g['pos0'][..., None], g['vel0'][..., None])
+    assert np.array_equal(r[:, 0], g['rew']) and np.array_equal(inf[..., 0], g['info'])
+
+
+def test_kat3_spaces():
+    """SURVEY KAT-3: observation dims."""
+    assert O.simple_tag_spec().obs_dims == [16, 16, 16, 14]
+    assert O.simple_spread_spec().obs_dims == [18, 18, 18]
+    d = O.simple_tag_spec(48, 16, 32).obs_dims
+    assert set(d[:48]) == {226} and set(d[48:]) == {224}
+
+
+def test_kat4_far_apart_zero_action(golden_dir):
+    """SURVEY KAT-4: pos bitwise unchanged, vel tiny but not exactly zero (softplus tail)."""
+    g = _load(golden_dir, 'kat4_far_zero')
+    bo = O.BatchedOracle(O.simple_tag_spec())
+    p, v = bo.world_step(g['pos0'][..., None], g['vel0'][..., None], np.zeros((4, 5, 1)))
+    assert np.array_equal(p[..., 0], g['pos']) and np.array_equal(v[..., 0], g['vel'])
+    assert np.array_equal(g['pos'], g['pos0'])
+    assert 0 < np.abs(g['vel']).max() < 1e-100
+
+
+def test_serial_reset_uses_reference_draw_order(golden_dir):
+    """np.random.seed(s); make_world (one reset) ; env.reset() -> same pos0 as the reference
+    (agents ascending then landmarks ascending, 2 uniforms each: simple_tag.py:47-54)."""
+    for name, spec in (('g1_simple_tag', O.simple_tag_spec()), ('g2_simple_spread', O.simple_spread_spec())):
+        g = _load(golden_dir, name)
+        for s in g['seeds'][:8]:
+            np.random.seed(int(s))
+            env = O.SerialEnv(spec)
+            env.reset()             # make_world() -> reset_world (simple_tag.py:35)
+            obs = env.reset()       # env.reset()
+            pos, vel = env.get_state()
+            assert np.array_equal(pos, g['pos0'][s]) and np.array_equal(vel, g['vel0'][s])
+            assert np.array_equal(np.concatenate(obs), g['obs0'][s])
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    def run(c, k):
+        out = O.philox4x32_10([np.array([x], np.uint32) for x in c], [np.array([x], np.uint32) for x in k])
+        return [int(x[0]) for x in out]
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_reset_positions_ranges_and_independence():
+    spec = O.simple_tag_spec()
+    ids = np.arange(4096, dtype=np.uint64)
+    p = O.reset_positions(spec, seed=7, episode=3, env_ids=ids)
+    assert p.shape == (6, 2, 4096)
+    assert np.abs(p[:4]).max() < 1.0 and np.abs(p[4:]).max() < 0.9
+    assert abs(p[:4].mean()) < 0.02 and abs(p[:4].std() - 1 / np.sqrt(3)) < 0.02
+    # shard-independent: envs [1000,2000) computed alone equal the slice
+    q = O.reset_positions(spec, seed=7, episode=3, env_ids=ids[1000:2000])
+    assert np.array_equal(q, p[:, :, 1000:2000])
+    assert not np.array_equal(O.reset_positions(spec, 7, 4, ids), p)
