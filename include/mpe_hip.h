@@ -1,0 +1,183 @@
+/*
+ * mpe_hip.h -- C ABI of libmpe_hip.so: the MI355X (gfx950) batched implementation of the
+ * multiagent-particle-envs hot path  MultiAgentEnv.step -> World.step -> scenario gathers.
+ *
+ * The reference (asamakei/marl, /root/reference/multiagent-particle-envs) is pure Python and has
+ * no FFI for this path; its boundary is the duck-typed Python API
+ *     make_env(scenario_name, benchmark)                      make_env.py:15-44
+ *     MultiAgentEnv.step(action_n) / reset()                  multiagent/environment.py:92-129
+ *     Scenario.make_world/reset_world/reward/observation/benchmark_data   multiagent/scenario.py:4-10
+ * The functions below are what a ctypes binding under that API calls (marl_amd/_hip.py is that
+ * binding; INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - Plain C, plain pointers and sizes.  All array arguments are DEVICE pointers unless the name
+ *     starts with h_.  The library allocates nothing, keeps no global state, never synchronises:
+ *     every call only enqueues kernels on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream).  Safe to call concurrently from several threads / processes on different devices.
+ *   - Return value: 0 = OK, < 0 = MPE_ERR_* (bad argument; nothing was launched), > 0 = hipError_t
+ *     of the failed launch.  Never throws, never aborts.
+ *   - Struct-of-arrays device layout, env index fastest ("row" = one scalar for all envs):
+ *         pos  [E][2][ld]    E = n_agents + n_landmarks, agents first (core.py:109-111)
+ *         vel  [A][2][ld]    landmarks never move in the supported scenarios
+ *         act  [A][5][ld]    soft one-hot Discrete(5) action (environment.py:188-190)
+ *         noise[A][2][ld]    standard normals for u_noise (core.py:147); may be NULL
+ *         comm [A][dim_c][ld]  agent.state.c, written as zeros (all agents silent, core.py:226-227);
+ *                              may be NULL (then not written)
+ *         obs  [obs_total][ld]  agent i owns rows [obs_row0(i), obs_row0(i)+obs_dim(i))
+ *         rew  [A][ld]
+ *         info [A][info_w][ld]  info_w = 1 (simple_tag: collisions) or 4 (simple_spread:
+ *                               rew, collisions, min_dists, occupied_landmarks); may be NULL
+ *     `B` = number of envs processed, `ld` = row stride in elements (ld >= B), so a sub-range of a
+ *     larger batch can be processed by offsetting the pointers.
+ *   - _f32 / _f64 = arithmetic (and storage) type of the path.  f64 follows the reference's
+ *     float64 operation order (max abs deviation from numpy <= 1e-9 per step, in practice ~1e-15);
+ *     f32 is the throughput mode (<= 1e-4 relative).
+ */
+#ifndef MPE_HIP_H
+#define MPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPE_ABI_VERSION 1
+#define MPE_MAX_AGENTS 64
+#define MPE_MAX_ENTITIES 128
+
+/* scenario kinds (which observation/reward/info gather runs) */
+#define MPE_SIMPLE_TAG 0    /* build/lib/multiagent/scenarios/simple_tag.py    */
+#define MPE_SIMPLE_SPREAD 1 /* build/lib/multiagent/scenarios/simple_spread.py */
+
+/* error codes */
+#define MPE_OK 0
+#define MPE_ERR_NULL (-1)        /* a required pointer is NULL                       */
+#define MPE_ERR_DESC (-2)        /* descriptor fails mpe_desc_check                  */
+#define MPE_ERR_BATCH (-3)       /* B <= 0 or ld < B                                  */
+#define MPE_ERR_ALIGN (-4)       /* a device pointer is not aligned to its element   */
+#define MPE_ERR_UNSUPPORTED (-5) /* e.g. movable landmarks, non-silent agents        */
+#define MPE_ERR_ARG (-6)         /* any other bad scalar argument                    */
+
+/*
+ * World + scenario constants: what Scenario.make_world() sets up (simple_tag.py:7-36,
+ * simple_spread.py:7-28) plus the World defaults (core.py:88-106).  Host memory, read during the
+ * call only.  Entities are indexed agents first, then landmarks.
+ */
+typedef struct mpe_scenario_desc {
+  int32_t kind;        /* MPE_SIMPLE_TAG / MPE_SIMPLE_SPREAD */
+  int32_t n_agents;    /* A, 1..MPE_MAX_AGENTS */
+  int32_t n_landmarks; /* L, A+L <= MPE_MAX_ENTITIES */
+  int32_t dim_c;       /* world.dim_c (comm width; 2 in both scenarios) */
+  double dt;             /* core.py:100 */
+  double damping;        /* core.py:102 */
+  double contact_force;  /* core.py:104 */
+  double contact_margin; /* core.py:105 */
+  double agent_pos_range;    /* reset: agents    ~ U(-r, r)^2  (simple_tag.py:48)            */
+  double landmark_pos_range; /* reset: landmarks ~ U(-r, r)^2  (simple_tag.py:53 -> 0.9)     */
+  double size[MPE_MAX_ENTITIES];    /* entity.size (core.py:32)                               */
+  double mass[MPE_MAX_ENTITIES];    /* entity.mass (core.py:51-53)                            */
+  double accel[MPE_MAX_AGENTS];     /* action sensitivity: agent.accel, or 5.0 when None
+                                       (environment.py:193-196)                              */
+  double max_speed[MPE_MAX_AGENTS]; /* agent.max_speed; < 0 encodes None = no clamp
+                                       (core.py:217)                                         */
+  double u_noise[MPE_MAX_AGENTS];   /* agent.u_noise; 0 encodes None (core.py:147)            */
+  uint8_t movable[MPE_MAX_ENTITIES];
+  uint8_t collide[MPE_MAX_ENTITIES];
+  uint8_t adversary[MPE_MAX_AGENTS]; /* simple_tag: agent.adversary (simple_tag.py:21)        */
+} mpe_scenario_desc;
+
+int mpe_abi_version(void);
+const char *mpe_strerror(int code);
+/* sizeof(mpe_scenario_desc) as compiled into the library (bindings check their struct layout). */
+int64_t mpe_desc_sizeof(void);
+
+/* Validates a descriptor (counts, positive masses/margin, landmarks immovable). */
+int mpe_desc_check(const mpe_scenario_desc *desc);
+
+/* Observation geometry == len(scenario.observation(agent, world)) (environment.py:78);
+ * negative = error code. */
+int mpe_obs_dim(const mpe_scenario_desc *desc, int agent);
+int mpe_obs_row0(const mpe_scenario_desc *desc, int agent);
+int mpe_obs_total(const mpe_scenario_desc *desc);
+int mpe_info_width(const mpe_scenario_desc *desc);
+
+/*
+ * World.step for every env (core.py:124-140): MultiAgentEnv._set_action decode
+ * (environment.py:157-208) -> apply_action_force (core.py:143-149) -> apply_environment_force /
+ * get_collision_force (core.py:197-208, 233-249; this fork's one-sided response) ->
+ * integrate_state (core.py:211-222) -> update_agent_state (core.py:224-230).
+ * pos / vel are updated in place.
+ */
+int mpe_world_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *act,
+                       const float *noise, float *pos, float *vel, float *comm, void *stream);
+int mpe_world_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *act,
+                       const double *noise, double *pos, double *vel, double *comm, void *stream);
+
+/*
+ * Scenario gathers from the current state, for every agent of every env:
+ * observation (simple_tag.py:131-147 / simple_spread.py:83-99), reward (simple_tag.py:84-129 /
+ * simple_spread.py:71-81), benchmark_data (simple_tag.py:57-66 / simple_spread.py:46-62).
+ * Any of obs / rew / info may be NULL (skipped); MultiAgentEnv.reset() needs obs only
+ * (environment.py:119-129).
+ */
+int mpe_observe_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *pos,
+                    const float *vel, float *obs, float *rew, float *info, void *stream);
+int mpe_observe_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *pos,
+                    const double *vel, double *obs, double *rew, double *info, void *stream);
+
+/*
+ * MultiAgentEnv.step (environment.py:92-117) in one launch: mpe_world_step followed by
+ * mpe_observe on the post-step state, with the state kept on chip in between.
+ * `stats` (may be NULL): per-workgroup running sums of reward / collision statistics, double
+ * [mpe_stats_rows(...)][mpe_stats_width(desc)], accumulated (+=) by this call; reduce with
+ * mpe_stats_reduce.  Zero it with hipMemsetAsync before the first step of a window.
+ */
+int mpe_env_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *act,
+                     const float *noise, float *pos, float *vel, float *comm, float *obs,
+                     float *rew, float *info, double *stats, void *stream);
+int mpe_env_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *act,
+                     const double *noise, double *pos, double *vel, double *comm, double *obs,
+                     double *rew, double *info, double *stats, void *stream);
+
+/*
+ * Scenario.reset_world (simple_tag.py:39-54 / simple_spread.py:30-44): agents ~ U(-ra, ra)^2,
+ * landmarks ~ U(-rl, rl)^2, velocities and comm zero.  The reference draws from the global
+ * np.random stream; this build draws Philox4x32-10 with counter (env_id_lo, env_id_hi, episode,
+ * entity) and key = seed, env_id = env_id0 + index, so results do not depend on how envs are
+ * sharded over GPUs.  `mask` (may be NULL): uint8 [B], only envs with mask != 0 are reset.
+ */
+int mpe_reset_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
+                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, float *pos, float *vel,
+                  float *comm, void *stream);
+int mpe_reset_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
+                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, double *pos,
+                  double *vel, double *comm, void *stream);
+
+/*
+ * Episode statistics (what the reference's loops sum on the host: rew_n per agent,
+ * experiments/simple_train.py:284-286, and info_n per agent, :357).  Width = 2*A + 2 doubles:
+ * [0,A) sum of reward per agent, [A,2A) sum of collisions per agent (info column 0 for
+ * simple_tag, column 1 for simple_spread), [2A] sum over envs of colliding (good,adversary) pairs
+ * (simple_tag) or occupied landmarks (simple_spread), [2A+1] number of env-steps.
+ * mpe_stats_rows = number of per-workgroup rows mpe_env_step_* accumulates into for this (desc,
+ * B, dtype): dtype_bytes is 4 or 8.  mpe_stats_reduce sums the rows in a fixed order (bitwise
+ * reproducible) into out[width]; that vector is what ranks all-reduce over RCCL.
+ */
+int mpe_stats_width(const mpe_scenario_desc *desc);
+int64_t mpe_stats_rows(const mpe_scenario_desc *desc, int64_t B, int dtype_bytes);
+int mpe_stats_reduce(const double *stats, int64_t rows, int width, double *out, void *stream);
+
+/*
+ * Test hook (no reference counterpart): on != 0 routes the stock worlds (simple_tag 3+1/2,
+ * simple_spread 3/3), which normally run the register-resident kernel, through the generic
+ * LDS-tile kernel as well, so both kernels can be checked against the same golden vectors.
+ * Process-wide; not for production use.
+ */
+void mpe_debug_force_tile_kernel(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPE_HIP_H */

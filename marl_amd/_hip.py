@@ -1,0 +1,109 @@
+"""ctypes binding of libmpe_hip.so (C ABI: include/mpe_hip.h).
+
+This is the stub a maintainer of the reference would add under its Python API
+(multiagent/environment.py:92-129, multiagent/core.py:124-140).  There is NO CPU
+fallback: if the shared library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+MPE_MAX_AGENTS = 64
+MPE_MAX_ENTITIES = 128
+MPE_SIMPLE_TAG = 0
+MPE_SIMPLE_SPREAD = 1
+ABI_VERSION = 1
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libmpe_hip.so')
+
+
+class ScenarioDesc(C.Structure):
+    """mpe_scenario_desc (include/mpe_hip.h)."""
+    _fields_ = [
+        ('kind', C.c_int32), ('n_agents', C.c_int32), ('n_landmarks', C.c_int32), ('dim_c', C.c_int32),
+        ('dt', C.c_double), ('damping', C.c_double), ('contact_force', C.c_double),
+        ('contact_margin', C.c_double),
+        ('agent_pos_range', C.c_double), ('landmark_pos_range', C.c_double),
+        ('size', C.c_double * MPE_MAX_ENTITIES), ('mass', C.c_double * MPE_MAX_ENTITIES),
+        ('accel', C.c_double * MPE_MAX_AGENTS), ('max_speed', C.c_double * MPE_MAX_AGENTS),
+        ('u_noise', C.c_double * MPE_MAX_AGENTS),
+        ('movable', C.c_uint8 * MPE_MAX_ENTITIES), ('collide', C.c_uint8 * MPE_MAX_ENTITIES),
+        ('adversary', C.c_uint8 * MPE_MAX_AGENTS),
+    ]
+
+
+class MpeError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.mpe_strerror(code).decode() if lib is not None else '?'
+        super().__init__('%s failed: %s (code %d)' % (where, msg, code))
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            'marl_amd: %s not found. Build it with `make -C marl_amd/csrc` (hipcc, gfx950); '
+            'there is no CPU fallback.' % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    vp, i64, u64, u32, ci = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int
+    dp = C.POINTER(ScenarioDesc)
+    L.mpe_abi_version.restype = ci
+    L.mpe_abi_version.argtypes = []
+    L.mpe_strerror.restype = C.c_char_p
+    L.mpe_strerror.argtypes = [ci]
+    for name in ('mpe_desc_check', 'mpe_obs_total', 'mpe_info_width', 'mpe_stats_width'):
+        f = getattr(L, name)
+        f.restype, f.argtypes = ci, [dp]
+    for name in ('mpe_obs_dim', 'mpe_obs_row0'):
+        f = getattr(L, name)
+        f.restype, f.argtypes = ci, [dp, ci]
+    for suf in ('f32', 'f64'):
+        f = getattr(L, 'mpe_world_step_' + suf)
+        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_observe_' + suf)
+        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_env_step_' + suf)
+        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_reset_' + suf)
+        f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, vp, vp, vp, vp]
+    L.mpe_stats_rows.restype = i64
+    L.mpe_stats_rows.argtypes = [dp, i64, ci]
+    L.mpe_stats_reduce.restype = ci
+    L.mpe_stats_reduce.argtypes = [vp, i64, ci, vp, vp]
+    L.mpe_debug_force_tile_kernel.restype = None
+    L.mpe_debug_force_tile_kernel.argtypes = [ci]
+    L.mpe_desc_sizeof.restype = i64
+    L.mpe_desc_sizeof.argtypes = []
+    if L.mpe_desc_sizeof() != C.sizeof(ScenarioDesc):
+        raise ImportError('marl_amd: mpe_scenario_desc layout mismatch (%d vs %d bytes)'
+                          % (L.mpe_desc_sizeof(), C.sizeof(ScenarioDesc)))
+    if L.mpe_abi_version() != ABI_VERSION:
+        raise ImportError('marl_amd: libmpe_hip.so ABI %d != expected %d' % (L.mpe_abi_version(), ABI_VERSION))
+    return L
+
+
+lib = None
+lib = _load()
+
+
+def check(code, where):
+    if code != 0:
+        raise MpeError(code, where)
+
+
+def suffix(dtype):
+    import torch
+    if dtype == torch.float32:
+        return 'f32'
+    if dtype == torch.float64:
+        return 'f64'
+    raise TypeError('marl_amd supports torch.float32 / torch.float64, got %r' % (dtype,))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,317 @@
+"""Batched world model: the reference's ``multiagent/core.py`` data model (core.py:4-121) with the
+per-entity numpy arrays replaced by struct-of-arrays device tensors shared by all env instances.
+
+    world.pos  [E, 2, B]   entities = agents then landmarks (core.py:109-111)
+    world.vel  [A, 2, B]
+    world.comm [A, dim_c, B]
+    world.act  [A, 5, B]   soft one-hot Discrete(5) actions (environment.py:188-190)
+
+``entity.state.p_pos`` / ``p_vel`` / ``agent.state.c`` are ``[B, 2]`` views into those buffers
+(strides (1, B)), so reference-style scenario code keeps working on whole batches.
+``World.step()`` (core.py:124-140) is one HIP kernel launch (libmpe_hip.so: mpe_world_step_*).
+"""
+import torch
+
+from . import _hip
+
+
+class EntityState(object):
+    """core.py:4-9; arrays are views into the world's SoA buffers."""
+
+    def __init__(self, entity):
+        self._e = entity
+
+    def _rows(self, name):
+        w, i = self._e._world, self._e._index
+        if w is None or w.pos is None:
+            raise RuntimeError('entity state is only available after World.allocate()')
+        if name == 'pos':
+            return w.pos[i]
+        if i >= w.vel.shape[0]:
+            return None
+        return w.vel[i]
+
+    @property
+    def p_pos(self):
+        return self._rows('pos').t()
+
+    @p_pos.setter
+    def p_pos(self, value):
+        r = self._rows('pos')
+        r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], 2).t())
+        self._e._world.mark_dirty()
+
+    @property
+    def p_vel(self):
+        r = self._rows('vel')
+        if r is None:  # landmarks never move: zeros (simple_tag.py:54)
+            w = self._e._world
+            return torch.zeros(w.num_envs, 2, dtype=w.dtype, device=w.device)
+        return r.t()
+
+    @p_vel.setter
+    def p_vel(self, value):
+        r = self._rows('vel')
+        if r is not None:
+            r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], 2).t())
+            self._e._world.mark_dirty()
+
+
+class AgentState(EntityState):
+    """core.py:12-16."""
+
+    @property
+    def c(self):
+        return self._e._world.comm[self._e._index].t()
+
+    @c.setter
+    def c(self, value):
+        r = self._e._world.comm[self._e._index]
+        r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], r.shape[0]).t())
+
+
+class Action(object):
+    """core.py:19-24.  ``u`` is decoded inside the step kernel; kept for API shape."""
+
+    def __init__(self):
+        self.u = None
+        self.c = None
+
+
+class Entity(object):
+    """core.py:27-53 (same attribute names and defaults)."""
+
+    def __init__(self):
+        self.name = ''
+        self.size = 0.050
+        self.movable = False
+        self.collide = True
+        self.density = 25.0
+        self.color = None
+        self.max_speed = None
+        self.accel = None
+        self.state = EntityState(self)
+        self.initial_mass = 1.0
+        self.obs_r = 0.0
+        self._world = None
+        self._index = -1
+
+    @property
+    def mass(self):
+        return self.initial_mass
+
+
+class Landmark(Entity):
+    """core.py:56-58."""
+
+    def __init__(self):
+        super(Landmark, self).__init__()
+
+
+class Agent(Entity):
+    """core.py:61-85."""
+
+    def __init__(self):
+        super(Agent, self).__init__()
+        self.movable = True
+        self.silent = False
+        self.blind = False
+        self.pblind = True
+        self.u_noise = None
+        self.c_noise = None
+        self.u_range = 1.0
+        self.state = AgentState(self)
+        self.action = Action()
+        self.action_callback = None
+
+
+class World(object):
+    """core.py:88-140, batched over ``num_envs`` instances."""
+
+    def __init__(self):
+        self.agents = []
+        self.landmarks = []
+        self.dim_c = 0
+        self.dim_p = 2
+        self.dim_color = 3
+        self.dt = 0.1
+        self.damping = 0.25
+        self.contact_force = 1e+2
+        self.contact_margin = 1e-3
+        # batched state (allocate())
+        self.num_envs = 0
+        self.device = None
+        self.dtype = None
+        self.pos = self.vel = self.comm = self.act = self.noise = None
+        # gather outputs (allocated on first use): obs [obs_total,B], rew [A,B], info [A,W,B]
+        self.obs = self.rew = self.info = None
+        self.obs_views = None
+        self.stats = None          # per-workgroup statistics rows (enable_stats())
+        self._tick = 0             # bumped whenever the state changes
+        self._gather_tick = -1     # tick the gather buffers correspond to
+        # device reset RNG: Philox key / per-reset counter / global id of env 0 (multi-GPU shards)
+        self.seed = 0
+        self.episode = 0
+        self.env_id0 = 0
+        # scenario kind + reset ranges for the C ABI descriptor (set by the built-in scenarios)
+        self.hip_kind = None
+        self.agent_pos_range = 1.0
+        self.landmark_pos_range = 1.0
+        self._desc = None
+
+    # -- core.py:109-121 -----------------------------------------------------------------------------
+    @property
+    def entities(self):
+        return self.agents + self.landmarks
+
+    @property
+    def policy_agents(self):
+        return [agent for agent in self.agents if agent.action_callback is None]
+
+    @property
+    def scripted_agents(self):
+        return [agent for agent in self.agents if agent.action_callback is not None]
+
+    # -- batched storage -----------------------------------------------------------------------------
+    def allocate(self, num_envs, device=None, dtype=torch.float64):
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('marl_amd runs on an AMD GPU (torch device "cuda"); there is no CPU path')
+        _hip.suffix(dtype)
+        A, E = len(self.agents), len(self.entities)
+        B = int(num_envs)
+        self.num_envs, self.device, self.dtype = B, device, dtype
+        z = dict(dtype=dtype, device=device)
+        self.pos = torch.zeros(E, 2, B, **z)
+        self.vel = torch.zeros(A, 2, B, **z)
+        self.comm = torch.zeros(A, max(self.dim_c, 1), B, **z)[:, :self.dim_c]
+        self.act = torch.zeros(A, 5, B, **z)
+        self.noise = None
+        self.obs = self.rew = self.info = self.obs_views = self.stats = None
+        for i, e in enumerate(self.entities):
+            e._world, e._index = self, i
+        self._desc = None
+        self.mark_dirty()
+        return self
+
+    def mark_dirty(self):
+        """Call after writing world.pos / world.vel directly (setters on entity.state do it)."""
+        self._tick += 1
+
+    def _alloc_outputs(self):
+        d = self.descriptor()
+        A, B = len(self.agents), self.num_envs
+        z = dict(dtype=self.dtype, device=self.device)
+        total = _hip.lib.mpe_obs_total(d)
+        self.obs = torch.zeros(total, B, **z)
+        self.rew = torch.zeros(A, B, **z)
+        self.info = torch.zeros(A, _hip.lib.mpe_info_width(d), B, **z)
+        self.obs_views = []
+        for i in range(A):
+            r0, n = _hip.lib.mpe_obs_row0(d, i), _hip.lib.mpe_obs_dim(d, i)
+            self.obs_views.append(self.obs[r0:r0 + n].t())      # [B, obs_dim_i], strides (1, B)
+
+    def gather(self, force=False):
+        """Observation / reward / benchmark_data of every agent for the current state: one launch
+        of mpe_observe_* (scenario callbacks simple_tag.py:57-147 / simple_spread.py:46-99)."""
+        if self.obs is None:
+            self._alloc_outputs()
+        if self._gather_tick == self._tick and not force:
+            return
+        d = self.descriptor()
+        fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
+        _hip.check(fn(d, self.num_envs, self.num_envs, self.pos.data_ptr(), self.vel.data_ptr(),
+                      self.obs.data_ptr(), self.rew.data_ptr(), self.info.data_ptr(),
+                      _hip.stream_of(self.device)), 'mpe_observe')
+        self._gather_tick = self._tick
+
+    def enable_stats(self):
+        """Allocate (or zero) the per-workgroup statistics rows env_step accumulates into."""
+        d = self.descriptor()
+        rows = _hip.lib.mpe_stats_rows(d, self.num_envs, 4 if self.dtype == torch.float32 else 8)
+        width = _hip.lib.mpe_stats_width(d)
+        if self.stats is None or tuple(self.stats.shape) != (rows, width):
+            self.stats = torch.zeros(rows, width, dtype=torch.float64, device=self.device)
+        else:
+            self.stats.zero_()
+        return self.stats
+
+    def read_stats(self, out=None):
+        """Deterministic reduction of the statistics rows -> [2A+2] float64 device vector."""
+        if out is None:
+            out = torch.empty(self.stats.shape[1], dtype=torch.float64, device=self.device)
+        _hip.check(_hip.lib.mpe_stats_reduce(self.stats.data_ptr(), self.stats.shape[0], self.stats.shape[1],
+                                             out.data_ptr(), _hip.stream_of(self.device)), 'mpe_stats_reduce')
+        return out
+
+    def env_step(self, want_info=True):
+        """MultiAgentEnv.step's device work in ONE launch (mpe_env_step_*): action decode + World.step
+        + all observation / reward / info gathers, from the actions in ``world.act``."""
+        if self.obs is None:
+            self._alloc_outputs()
+        d = self.descriptor()
+        keep, nptr = self._noise_ptr()
+        fn = getattr(_hip.lib, 'mpe_env_step_' + _hip.suffix(self.dtype))
+        _hip.check(fn(d, self.num_envs, self.num_envs, self.act.data_ptr(), nptr, self.pos.data_ptr(),
+                      self.vel.data_ptr(), None, self.obs.data_ptr(), self.rew.data_ptr(),
+                      self.info.data_ptr() if want_info else None, _hip.ptr(self.stats),
+                      _hip.stream_of(self.device)), 'mpe_env_step')
+        self._tick += 1
+        if want_info:
+            self._gather_tick = self._tick
+
+    def descriptor(self):
+        """mpe_scenario_desc for this world (rebuilt when entity properties may have changed)."""
+        if self._desc is not None:
+            return self._desc
+        if self.hip_kind is None:
+            raise RuntimeError('world.hip_kind is not set (built-in scenarios set it in make_world)')
+        d = _hip.ScenarioDesc()
+        A, L = len(self.agents), len(self.landmarks)
+        if A > _hip.MPE_MAX_AGENTS or A + L > _hip.MPE_MAX_ENTITIES:
+            raise ValueError('world too large for libmpe_hip (max %d agents / %d entities)'
+                             % (_hip.MPE_MAX_AGENTS, _hip.MPE_MAX_ENTITIES))
+        d.kind, d.n_agents, d.n_landmarks, d.dim_c = self.hip_kind, A, L, self.dim_c
+        d.dt, d.damping = self.dt, self.damping
+        d.contact_force, d.contact_margin = self.contact_force, self.contact_margin
+        d.agent_pos_range, d.landmark_pos_range = self.agent_pos_range, self.landmark_pos_range
+        for i, e in enumerate(self.entities):
+            d.size[i], d.mass[i] = e.size, e.mass
+            d.movable[i], d.collide[i] = int(bool(e.movable)), int(bool(e.collide))
+        for i, a in enumerate(self.agents):
+            if not a.silent:
+                raise NotImplementedError('non-silent agents (comm actions) are outside the HIP hot path')
+            if a.action_callback is not None:
+                raise NotImplementedError('scripted agents (action_callback) are outside the HIP hot path')
+            d.accel[i] = 5.0 if a.accel is None else a.accel          # environment.py:193-196
+            d.max_speed[i] = -1.0 if a.max_speed is None else a.max_speed
+            d.u_noise[i] = a.u_noise if a.u_noise else 0.0            # core.py:147
+            d.adversary[i] = int(bool(getattr(a, 'adversary', False)))
+        _hip.check(_hip.lib.mpe_desc_check(d), 'mpe_desc_check')
+        self._desc = d
+        return d
+
+    def invalidate_descriptor(self):
+        self._desc = None
+
+    def _noise_ptr(self):
+        """Standard normals for u_noise (core.py:147).  ``world.noise`` may be set by the caller
+        ([A,2,B], e.g. recorded draws for parity); otherwise fresh torch.randn per step."""
+        if not any(a.u_noise for a in self.agents):
+            return None, None
+        n = self.noise
+        if n is None:
+            n = torch.randn(len(self.agents), 2, self.num_envs, dtype=self.dtype, device=self.device)
+        return n, n.data_ptr()
+
+    # -- core.py:124-140 -----------------------------------------------------------------------------
+    def step(self):
+        """Advance every env by one tick using the actions in ``world.act``."""
+        d = self.descriptor()
+        keep, nptr = self._noise_ptr()
+        fn = getattr(_hip.lib, 'mpe_world_step_' + _hip.suffix(self.dtype))
+        _hip.check(fn(d, self.num_envs, self.num_envs, self.act.data_ptr(), nptr, self.pos.data_ptr(),
+                      self.vel.data_ptr(), None, _hip.stream_of(self.device)), 'mpe_world_step')
+        self.mark_dirty()

@@ -1,0 +1,132 @@
+// Device-side building blocks shared by the MPE kernels (gfx950 only; wave = 64 lanes).
+//
+// Arithmetic follows the reference's float64 operation order (core.py:233-249, :211-222;
+// simple_tag.py:69-73,103-108) so that the f64 instantiation reproduces numpy to the last bits
+// that the device exp/log1p allow.  The library is compiled with -ffp-contract=off: no FMA is
+// formed unless written explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpe_hip.h"
+
+namespace mpe {
+
+// Device copy of mpe_scenario_desc in the arithmetic type T, passed BY VALUE in the kernarg
+// segment (uniform indices become scalar loads; no device allocation, no global state).
+template <typename T>
+struct DevDesc {
+  int32_t kind, A, L, E, dim_c, obs_total, info_w, n_adv;
+  T dt, damp1 /* 1 - damping */, cforce, k;
+  T size[MPE_MAX_ENTITIES];
+  T mass[MPE_MAX_AGENTS];
+  T accel[MPE_MAX_AGENTS];
+  T max_speed[MPE_MAX_AGENTS];  // < 0: None
+  T u_noise[MPE_MAX_AGENTS];    // 0: None
+  int32_t obs_row0[MPE_MAX_AGENTS];
+  uint32_t movable[MPE_MAX_ENTITIES / 32];
+  uint32_t collide[MPE_MAX_ENTITIES / 32];
+  uint32_t adversary[MPE_MAX_AGENTS / 32];
+};
+
+template <typename T>
+struct KParams {
+  const T *act, *noise;
+  T *pos, *vel, *comm, *obs, *rew, *info;
+  double *stats;
+  int64_t B, ld;
+  DevDesc<T> d;
+};
+
+__device__ __forceinline__ bool bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_log1p(T x);
+template <> __device__ __forceinline__ float t_log1p<float>(float x) { return log1pf(x); }
+template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
+template <typename T> __device__ __forceinline__ T t_abs(T x);
+template <> __device__ __forceinline__ float t_abs<float>(float x) { return fabsf(x); }
+template <> __device__ __forceinline__ double t_abs<double>(double x) { return fabs(x); }
+
+// get_collision_force (core.py:239-246): force on entity a from the pair (a,b), d = pos_a - pos_b.
+//   dist = sqrt(dx^2+dy^2); pen = logaddexp(0, -(dist-dmin)/k)*k; f = cforce*d/dist*pen
+// np.logaddexp(0,x) == max(x,0) + log1p(exp(-|x|)).
+template <typename T>
+__device__ __forceinline__ void pair_force(T dx, T dy, T dmin, T k, T cforce, T &fx, T &fy) {
+  const T dist = t_sqrt<T>(dx * dx + dy * dy);
+  const T x = -(dist - dmin) / k;
+  const T pen = ((x > T(0) ? x : T(0)) + t_log1p<T>(t_exp<T>(-t_abs<T>(x)))) * k;
+  fx = (cforce * dx) / dist * pen;
+  fy = (cforce * dy) / dist * pen;
+}
+
+// integrate_state (core.py:214-221) for one movable entity; returns new velocity.
+template <typename T>
+__device__ __forceinline__ void integrate_vel(T &vx, T &vy, T Fx, T Fy, T mass, T damp1, T dt,
+                                              T max_speed) {
+  vx = vx * damp1;
+  vy = vy * damp1;
+  vx = vx + (Fx / mass) * dt;
+  vy = vy + (Fy / mass) * dt;
+  if (max_speed >= T(0)) {
+    const T sp = t_sqrt<T>(vx * vx + vy * vy);
+    if (sp > max_speed) {  // divide first, then multiply (core.py:220-221)
+      vx = vx / sp * max_speed;
+      vy = vy / sp * max_speed;
+    }
+  }
+}
+
+// is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): strict <.
+template <typename T>
+__device__ __forceinline__ bool touching(T dx, T dy, T dmin) {
+  return t_sqrt<T>(dx * dx + dy * dy) < dmin;
+}
+
+// bound() of simple_tag.agent_reward (simple_tag.py:103-108), x = |pos|.
+template <typename T>
+__device__ __forceinline__ T tag_bound(T x) {
+  if (x < T(0.9)) return T(0);
+  if (x < T(1.0)) return (x - T(0.9)) * T(10);
+  const T e = t_exp<T>(T(2) * x - T(2));
+  return e < T(10) ? e : T(10);
+}
+
+// Sum over the `width` consecutive lanes (width = 32 or 64) that contain this lane.
+__device__ __forceinline__ double group_sum(double v, int width) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+    if (off < width) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011); restated in oracle/mpe_oracle.py:philox4x32_10.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 53-bit uniform in [0,1) from two words; p = -r + 2r*u (np.random.uniform's low + (high-low)*u).
+__device__ __forceinline__ double uniform_pm(uint32_t hi, uint32_t lo, double r) {
+  const double u = ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+  return -r + (2.0 * r) * u;
+}
+
+}  // namespace mpe

@@ -1,0 +1,283 @@
+// Generic (any A <= 64, E <= 128) env-step kernel: one workgroup = one tile of TILE env instances,
+// entity state staged in LDS.
+//
+//   workgroup = 256 threads = NCH chunks x TILE lanes; lane <-> env (so every global access is a
+//   coalesced 256-byte row segment of the SoA arrays), chunk <-> subset of agents (a % NCH).
+//   TILE = 64 for f32 (chunk = one wavefront), 32 for f64 (chunk = half a wavefront).
+//
+//   LDS:  sPos[2E][TILE]  sVel[max(2A, aux)][TILE]   (the reward scratch sAux aliases sVel once the
+//         observations, the last reader of sVel, are out: E=96/A=64 is exactly 80 KiB = 2 blocks/CU)
+//
+//   phase 0  cooperative load of pos rows -> sPos
+//   phase 1  per (env, agent a): decode action, add u_noise, sum the one-sided contact forces over
+//            b = a+1..E-1 in ascending order (reference order, core.py:199-205), integrate the
+//            velocity; new vel -> sVel + HBM          (old positions still in sPos)
+//   phase 2  pos_a += vel_a*dt -> sPos + HBM
+//   phase 3  observation gather from sPos, sVel; then reward / info from sPos (+ sAux); optional
+//            per-workgroup statistics via wavefront reductions.
+//
+// The O(E^2) pair sum is kept sequential in b inside one lane: that is the reference's summation
+// order, it needs no cross-lane traffic at all, and the lanes are already full with envs.
+#pragma once
+#include "mpe_device.h"
+
+namespace mpe {
+
+constexpr int kTileThreads = 256;
+
+template <typename T, int TILE, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) {
+  constexpr int NCH = kTileThreads / TILE;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const DevDesc<T> &d = p.d;
+  const int A = d.A, L = d.L, E = d.E;
+  T *sPos = reinterpret_cast<T *>(smem_raw);
+  T *sVel = sPos + 2 * E * TILE;
+  T *sAux = sVel;  // valid only after the observation phase
+
+  const int lane = threadIdx.x % TILE;
+  const int chunk = threadIdx.x / TILE;
+  const int64_t ld = p.ld;
+  const int64_t ntiles = (p.B + TILE - 1) / TILE;
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t env = tile * TILE + lane;
+    const bool active = env < p.B;
+    const int64_t ge = active ? env : (p.B - 1);  // inactive lanes shadow the last env, never store
+
+    // ---- phase 0 ------------------------------------------------------------------------------
+    for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = p.pos[(int64_t)r * ld + ge];
+    if (!DO_STEP)
+      for (int r = chunk; r < 2 * A; r += NCH) sVel[r * TILE + lane] = p.vel[(int64_t)r * ld + ge];
+    __syncthreads();
+
+    if (DO_STEP) {
+      // ---- phase 1: forces + velocity ---------------------------------------------------------
+      for (int a = chunk; a < A; a += NCH) {
+        T vx = p.vel[(int64_t)(2 * a) * ld + ge];
+        T vy = p.vel[(int64_t)(2 * a + 1) * ld + ge];
+        if (bit(d.movable, a)) {
+          // environment.py:188-196
+          const T *ar = p.act + (int64_t)(5 * a) * ld + ge;
+          T Fx = (ar[1 * ld] - ar[2 * ld]) * d.accel[a];
+          T Fy = (ar[3 * ld] - ar[4 * ld]) * d.accel[a];
+          // core.py:147-148
+          if (p.noise != nullptr && d.u_noise[a] != T(0)) {
+            Fx = Fx + p.noise[(int64_t)(2 * a) * ld + ge] * d.u_noise[a];
+            Fy = Fy + p.noise[(int64_t)(2 * a + 1) * ld + ge] * d.u_noise[a];
+          }
+          // core.py:199-205
+          if (bit(d.collide, a)) {
+            const T pax = sPos[(2 * a) * TILE + lane], pay = sPos[(2 * a + 1) * TILE + lane];
+            const T sa = d.size[a];
+            for (int b = a + 1; b < E; ++b) {
+              if (!bit(d.collide, b)) continue;
+              T fx, fy;
+              pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
+                            sa + d.size[b], d.k, d.cforce, fx, fy);
+              Fx = fx + Fx;
+              Fy = fy + Fy;
+            }
+          }
+          integrate_vel<T>(vx, vy, Fx, Fy, d.mass[a], d.damp1, d.dt, d.max_speed[a]);
+          if (active) {
+            p.vel[(int64_t)(2 * a) * ld + env] = vx;
+            p.vel[(int64_t)(2 * a + 1) * ld + env] = vy;
+          }
+        }
+        sVel[(2 * a) * TILE + lane] = vx;
+        sVel[(2 * a + 1) * TILE + lane] = vy;
+      }
+      __syncthreads();
+      // ---- phase 2: positions (core.py:222), comm (core.py:226-227) -----------------------------
+      for (int a = chunk; a < A; a += NCH) {
+        if (bit(d.movable, a)) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int r = 2 * a + c;
+            const T np_ = sPos[r * TILE + lane] + sVel[r * TILE + lane] * d.dt;
+            sPos[r * TILE + lane] = np_;
+            if (active) p.pos[(int64_t)r * ld + env] = np_;
+          }
+        }
+        if (p.comm != nullptr && active)
+          for (int c = 0; c < d.dim_c; ++c) p.comm[(int64_t)(a * d.dim_c + c) * ld + env] = T(0);
+      }
+      __syncthreads();
+    }
+
+    if (DO_OBS) {
+      const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr,
+                 want_stats = p.stats != nullptr;
+      double *srow = want_stats ? p.stats + (int64_t)blockIdx.x * (2 * A + 2) : nullptr;
+      // ---- phase 3a: observations (simple_tag.py:131-147 / simple_spread.py:83-99) -----------------
+      if (p.obs != nullptr && active) {
+        for (int i = chunk; i < A; i += NCH) {
+          T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
+          const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+          o[0] = sVel[(2 * i) * TILE + lane];
+          o[ld] = sVel[(2 * i + 1) * TILE + lane];
+          o[2 * ld] = pix;
+          o[3 * ld] = piy;
+          o += 4 * ld;
+          for (int l = A; l < E; ++l) {
+            o[0] = sPos[(2 * l) * TILE + lane] - pix;
+            o[ld] = sPos[(2 * l + 1) * TILE + lane] - piy;
+            o += 2 * ld;
+          }
+          for (int j = 0; j < A; ++j) {
+            if (j == i) continue;
+            o[0] = sPos[(2 * j) * TILE + lane] - pix;
+            o[ld] = sPos[(2 * j + 1) * TILE + lane] - piy;
+            o += 2 * ld;
+          }
+          if (d.kind == MPE_SIMPLE_TAG) {
+            for (int j = 0; j < A; ++j) {
+              if (j == i || bit(d.adversary, j)) continue;
+              o[0] = sVel[(2 * j) * TILE + lane];
+              o[ld] = sVel[(2 * j + 1) * TILE + lane];
+              o += 2 * ld;
+            }
+          } else {
+            for (int z = 0; z < d.dim_c * (A - 1); ++z) { o[0] = T(0); o += ld; }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- phase 3b: reward / info (sAux aliases sVel from here on) ---------------------------------------------------------------
+      if (want_rew || want_info || want_stats) {
+        if (d.kind == MPE_SIMPLE_TAG) {
+          // hit(g,a) = is_collision(good g, adversary a) (simple_tag.py:69-73)
+          int part = 0;  // this chunk's share of sum_{g,a} hit
+          for (int i = chunk; i < A; i += NCH) {
+            const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+            const bool i_adv = bit(d.adversary, i);
+            int n = 0;
+            for (int j = 0; j < A; ++j) {
+              if (bit(d.adversary, j) == i_adv) continue;
+              n += touching<T>(pix - sPos[(2 * j) * TILE + lane], piy - sPos[(2 * j + 1) * TILE + lane],
+                               d.size[i] + d.size[j])
+                       ? 1 : 0;
+            }
+            T r_i = T(0);
+            if (i_adv) {
+              part += n;  // benchmark_data (simple_tag.py:57-64); reward filled in after the reduce
+            } else {      // agent_reward (simple_tag.py:89-113)
+              if (bit(d.collide, i)) r_i = -T(10) * T(n);
+              r_i = r_i - tag_bound<T>(t_abs<T>(pix));
+              r_i = r_i - tag_bound<T>(t_abs<T>(piy));
+              if (want_rew && active) p.rew[(int64_t)i * ld + env] = r_i;
+            }
+            if (want_info && active) p.info[(int64_t)i * ld + env] = i_adv ? T(n) : T(0);
+            if (want_stats) {
+              const double s_c = group_sum(active && i_adv ? (double)n : 0.0, TILE);
+              if (lane == 0) srow[A + i] += s_c;
+              if (!i_adv) {
+                const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+                if (lane == 0) srow[i] += s_r;
+              }
+            }
+          }
+          int *sCnt = reinterpret_cast<int *>(sAux);
+          sCnt[chunk * TILE + lane] = part;
+          __syncthreads();
+          int total = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) total += sCnt[c * TILE + lane];
+          // adversary_reward (simple_tag.py:115-129): same value for every adversary
+          for (int i = chunk; i < A; i += NCH) {
+            if (!bit(d.adversary, i)) continue;
+            const T r_i = bit(d.collide, i) ? T(10) * T(total) : T(0);
+            if (want_rew && active) p.rew[(int64_t)i * ld + env] = r_i;
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              if (lane == 0) srow[i] += s_r;
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_t = group_sum(active ? (double)total : 0.0, TILE);
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        } else {
+          // simple_spread: m_l = min_a dist(a, landmark l) (simple_spread.py:74-76), summed in
+          // ascending l by every lane so the float order matches the reference.
+          for (int l = chunk; l < L; l += NCH) {
+            const T plx = sPos[(2 * (A + l)) * TILE + lane], ply = sPos[(2 * (A + l) + 1) * TILE + lane];
+            T m = T(0);
+            for (int a = 0; a < A; ++a) {
+              const T dx = sPos[(2 * a) * TILE + lane] - plx, dy = sPos[(2 * a + 1) * TILE + lane] - ply;
+              const T dist = t_sqrt<T>(dx * dx + dy * dy);
+              m = (a == 0 || dist < m) ? dist : m;
+            }
+            sAux[l * TILE + lane] = m;
+          }
+          __syncthreads();
+          T r0 = T(0), md = T(0);
+          int occ = 0;
+          for (int l = 0; l < L; ++l) {
+            const T m = sAux[l * TILE + lane];
+            md = md + m;
+            r0 = r0 - m;
+            occ += (m < T(0.1)) ? 1 : 0;
+          }
+          for (int i = chunk; i < A; i += NCH) {
+            const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+            T r_i = r0;
+            int c_i = 0;
+            if (bit(d.collide, i)) {
+              for (int a = 0; a < A; ++a) {  // includes a == i (simple_spread.py:78-80)
+                if (touching<T>(sPos[(2 * a) * TILE + lane] - pix, sPos[(2 * a + 1) * TILE + lane] - piy,
+                                d.size[a] + d.size[i])) {
+                  r_i = r_i - T(1);
+                  c_i += 1;
+                }
+              }
+            }
+            if (active) {
+              if (want_rew) p.rew[(int64_t)i * ld + env] = r_i;
+              if (want_info) {
+                T *ir = p.info + (int64_t)(4 * i) * ld + env;
+                ir[0] = r_i; ir[ld] = T(c_i); ir[2 * ld] = md; ir[3 * ld] = T(occ);
+              }
+            }
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              const double s_c = group_sum(active ? (double)c_i : 0.0, TILE);
+              if (lane == 0) { srow[i] += s_r; srow[A + i] += s_c; }
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_t = group_sum(active ? (double)occ : 0.0, TILE);
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        }
+      }
+    }
+    __syncthreads();  // LDS is reused by the next tile
+  }
+}
+
+template <typename T>
+constexpr int tile_envs() { return sizeof(T) == 4 ? 64 : 32; }
+
+// LDS bytes: pos rows + max(vel rows, aux rows); aux = NCH int rows (tag) or L rows of T (spread).
+template <typename T>
+inline size_t tile_lds_bytes(const mpe_scenario_desc *h) {
+  constexpr int TILE = tile_envs<T>();
+  constexpr int NCH = kTileThreads / TILE;
+  const int E = h->n_agents + h->n_landmarks;
+  size_t aux = h->kind == MPE_SIMPLE_TAG ? (size_t)NCH * TILE * sizeof(int)
+                                         : (size_t)h->n_landmarks * TILE * sizeof(T);
+  size_t velb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
+  if (velb < aux) velb = aux;
+  return (size_t)(2 * E) * TILE * sizeof(T) + velb;
+}
+
+inline int64_t tile_grid(int64_t B, int tile) {
+  const int64_t nt = (B + tile - 1) / tile;
+  return nt < 16384 ? nt : 16384;
+}
+
+}  // namespace mpe

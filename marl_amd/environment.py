@@ -1,0 +1,147 @@
+"""Batched MultiAgentEnv: the reference's gym-style env API (multiagent/environment.py:9-154) over
+``num_envs`` instances living on one MI355X.
+
+    env = make_env('simple_tag', benchmark=True, num_envs=1 << 20, dtype=torch.float32)
+    obs_n = env.reset()                       # list of n tensors [B, obs_dim_i]
+    obs_n, reward_n, done_n, info_n = env.step(action_n)
+
+``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190) or
+one tensor ``[B, n, 5]``.  Policies can write straight into ``env.action_views[i]`` (``[B,5]``
+views of the kernel's SoA action buffer) and pass that list: then step() copies nothing.
+Returned tensors are views of buffers that the next step()/reset() overwrites.
+
+When the callbacks are the methods of a built-in scenario (simple_tag / simple_spread) the whole
+step is one fused HIP launch; with user callbacks World.step() is one launch and the callbacks
+run as given, agent by agent, exactly like environment.py:105-110.
+"""
+import numpy as np
+import torch
+
+from . import spaces
+from .scenario import HipScenario
+
+
+class MultiAgentEnv(object):
+    metadata = {'render.modes': []}
+
+    def __init__(self, world, reset_callback=None, reward_callback=None,
+                 observation_callback=None, info_callback=None,
+                 done_callback=None, shared_viewer=True, observation_radius=1):
+        self.world = world
+        self.agents = self.world.policy_agents
+        self.n = len(world.policy_agents)
+        self.num_envs = world.num_envs
+        self.reset_callback = reset_callback
+        self.reward_callback = reward_callback
+        self.observation_callback = observation_callback
+        self.info_callback = info_callback
+        self.done_callback = done_callback
+        # environment.py:29-37
+        self.discrete_action_space = True
+        self.discrete_action_input = False
+        self.force_discrete_action = world.discrete_action if hasattr(world, 'discrete_action') else False
+        self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
+        self.time = 0
+        self.obs_r = observation_radius
+        if self.force_discrete_action:
+            raise NotImplementedError('force_discrete_action is outside the HIP hot path (SURVEY 8a a1)')
+
+        # fused path: every callback is a built-in scenario's own method
+        owners = {getattr(cb, '__self__', None) for cb in (reset_callback, reward_callback, observation_callback)}
+        if info_callback is not None:
+            owners.add(getattr(info_callback, '__self__', None))
+        self._scenario = owners.pop() if len(owners) == 1 else None
+        self._fused = (isinstance(self._scenario, HipScenario) and done_callback is None
+                       and all(getattr(cb, '__func__', None) is getattr(HipScenario, nm)
+                               for cb, nm in ((reward_callback, 'reward'), (observation_callback, 'observation'))))
+
+        # configure spaces (environment.py:39-80)
+        self.action_space = []
+        self.observation_space = []
+        for agent in self.agents:
+            if not agent.movable or not agent.silent:
+                raise NotImplementedError('only movable, silent agents are on the HIP hot path')
+            self.action_space.append(spaces.Discrete(world.dim_p * 2 + 1))
+            obs_dim = int(observation_callback(agent, self.world).shape[-1])
+            self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf, shape=(obs_dim,), dtype=np.float32))
+        self.action_views = [world.act[i].t() for i in range(self.n)]      # [B,5] views, strides (1,B)
+        self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=world.device)
+        self._empty_info = [{} for _ in range(self.n)]
+
+    # -- environment.py:157-208: the decode itself runs inside the kernel ------------------------------
+    def _set_actions(self, action_n):
+        act = self.world.act
+        if torch.is_tensor(action_n) and action_n.dim() == 3:
+            if tuple(action_n.shape) != (self.num_envs, self.n, 5):
+                raise ValueError('action tensor must be [num_envs, n, 5]')
+            act.copy_(action_n.permute(1, 2, 0))
+            return
+        if len(action_n) != self.n:
+            raise ValueError('need one action per agent')
+        for i, a in enumerate(action_n):
+            v = self.action_views[i]
+            if torch.is_tensor(a) and a.data_ptr() == v.data_ptr() and a.stride() == v.stride() \
+                    and a.shape == v.shape:
+                continue                                   # already in place
+            a = torch.as_tensor(a, dtype=act.dtype, device=act.device)
+            if a.shape[-1] != 5:
+                raise ValueError('each action must have 5 components (Discrete(5) soft one-hot)')
+            v.copy_(a.expand(self.num_envs, 5))
+
+    def step(self, action_n):
+        self.agents = self.world.policy_agents
+        self._set_actions(action_n)
+        world = self.world
+        if self._fused:
+            world.env_step(want_info=self.info_callback is not None)
+            obs_n = list(world.obs_views)
+            reward_n = [world.rew[i] for i in range(self.n)]
+            if self.info_callback is not None:
+                info_n = {'n': [self._scenario._format_info(world.info[i]) for i in range(self.n)]}
+            else:
+                info_n = {'n': list(self._empty_info)}
+        else:
+            world.step()
+            obs_n, reward_n, info_n = [], [], {'n': []}
+            for agent in self.agents:
+                obs_n.append(self._get_obs(agent))
+                reward_n.append(self._get_reward(agent))
+                info_n['n'].append(self._get_info(agent))
+        done_n = [self._get_done(agent) for agent in self.agents]
+        if self.shared_reward:            # environment.py:113-115
+            reward = torch.stack(list(reward_n)).sum(0)
+            reward_n = [reward] * self.n
+        return obs_n, reward_n, done_n, info_n
+
+    def reset(self):
+        self.reset_callback(self.world)
+        self.agents = self.world.policy_agents
+        if self._fused:
+            w = self.world
+            w.gather()
+            return list(w.obs_views)
+        return [self._get_obs(agent) for agent in self.agents]
+
+    # -- environment.py:131-154 ------------------------------------------------------------------------
+    def _get_info(self, agent):
+        if self.info_callback is None:
+            return {}
+        return self.info_callback(agent, self.world)
+
+    def _get_obs(self, agent):
+        if self.observation_callback is None:
+            return torch.zeros(self.num_envs, 0, dtype=self.world.dtype, device=self.world.device)
+        return self.observation_callback(agent, self.world)
+
+    def _get_done(self, agent):
+        if self.done_callback is None:
+            return self._done
+        return self.done_callback(agent, self.world)
+
+    def _get_reward(self, agent):
+        if self.reward_callback is None:
+            return torch.zeros(self.num_envs, dtype=self.world.dtype, device=self.world.device)
+        return self.reward_callback(agent, self.world)
+
+    def render(self, mode='human'):
+        raise NotImplementedError('rendering (environment.py:216-298) is out of scope for the batched simulator')

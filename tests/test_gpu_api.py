@@ -1,0 +1,180 @@
+"""GPU tests of the drop-in Python boundary (make_env / MultiAgentEnv.step / reset / Scenario),
+written like the loops that drive the reference (experiments/simple_train.py:257-300)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.double().cpu().numpy()
+
+
+@pytest.mark.parametrize('name,spec', [('simple_tag', O.simple_tag_spec()), ('simple_spread', O.simple_spread_spec())])
+def test_make_env_spaces_and_shapes(name, spec):
+    """SURVEY KAT-3: n, Discrete(5) action spaces, observation dims."""
+    from marl_amd import make_env
+    env = make_env(name, benchmark=True, num_envs=7, dtype=torch.float64)
+    assert env.n == spec.n_agents
+    assert [s.n for s in env.action_space] == [5] * env.n
+    assert [s.shape[0] for s in env.observation_space] == spec.obs_dims
+    obs_n = env.reset()
+    assert [tuple(o.shape) for o in obs_n] == [(7, d) for d in spec.obs_dims]
+    obs_n, rew_n, done_n, info_n = env.step([torch.rand(7, 5, device='cuda', dtype=torch.float64) for _ in range(env.n)])
+    assert [tuple(o.shape) for o in obs_n] == [(7, d) for d in spec.obs_dims]
+    assert all(tuple(r.shape) == (7,) for r in rew_n)
+    assert all(d.dtype == torch.bool and not d.any() for d in done_n)
+    assert len(info_n['n']) == env.n
+    env2 = make_env(name, benchmark=False, num_envs=3)
+    env2.reset()
+    assert env2.step(torch.rand(3, env2.n, 5, device='cuda', dtype=torch.float64))[3] == {'n': [{}] * env2.n}
+
+
+@pytest.mark.parametrize('name,spec', [('simple_tag', O.simple_tag_spec()), ('simple_spread', O.simple_spread_spec())])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+def test_episode_loop_matches_oracle(name, spec, dtype, tol):
+    """reset() + 25 x step() driven through the reference's loop shape; oracle replays the same
+    initial state and actions.  f32 is compared teacher-forced per step."""
+    from marl_amd import make_env
+    B, T = 512, 25
+    env = make_env(name, benchmark=True, num_envs=B, dtype=dtype, seed=3)
+    obs_n = env.reset()
+    w = env.world
+    bo = O.BatchedOracle(spec)
+    # reset state == the oracle's Philox restatement
+    want = O.reset_positions(spec, 3, w.episode - 1, np.arange(B, dtype=np.uint64),
+                             np.float64 if dtype == torch.float64 else np.float32)
+    assert np.array_equal(w.pos.cpu().numpy(), want) and (w.vel == 0).all()
+    obs0, _, _ = bo.observe(_np(w.pos), _np(w.vel))
+    for i in range(env.n):
+        np.testing.assert_allclose(_np(obs_n[i]).T, obs0[i], rtol=0, atol=tol)
+    pos, vel = _np(w.pos), _np(w.vel)
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    for t in range(T):
+        action_n = [torch.softmax(torch.randn(B, 5, generator=gen, device='cuda', dtype=dtype), -1) for _ in range(env.n)]
+        if dtype == torch.float32:
+            pos, vel = _np(w.pos), _np(w.vel)
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        act = np.stack([_np(a).T for a in action_n])
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act)
+        np.testing.assert_allclose(_np(w.pos), pos, rtol=tol, atol=tol)
+        np.testing.assert_allclose(_np(w.vel), vel, rtol=tol, atol=tol)
+        for i in range(env.n):
+            np.testing.assert_allclose(_np(new_obs_n[i]).T, obs[i], rtol=tol, atol=tol)
+        r = np.stack([_np(x) for x in rew_n])
+        if dtype == torch.float64:
+            np.testing.assert_allclose(r, rew, rtol=0, atol=tol)
+            if spec.kind == O.SIMPLE_TAG:
+                assert np.array_equal(np.stack([_np(x) for x in info_n['n']]), info[:, 0])
+            else:
+                got = np.stack([np.stack([_np(c) for c in tup]) for tup in info_n['n']])
+                np.testing.assert_allclose(got, info, rtol=0, atol=tol)
+        else:
+            assert np.mean(np.abs(r - rew) <= 1e-3) > 0.99
+
+
+def test_action_views_are_zero_copy_and_all_input_forms_agree():
+    from marl_amd import make_env
+    B = 300
+    outs = []
+    act = torch.softmax(torch.randn(B, 4, 5, device='cuda', dtype=torch.float64), -1)
+    for form in ('tensor', 'list', 'views', 'numpy'):
+        env = make_env('simple_tag', benchmark=True, num_envs=B, seed=11)
+        env.reset()
+        if form == 'tensor':
+            a = act
+        elif form == 'list':
+            a = [act[:, i] for i in range(4)]
+        elif form == 'numpy':
+            a = [act[:, i].cpu().numpy() for i in range(4)]
+        else:
+            for i in range(4):
+                env.action_views[i].copy_(act[:, i])
+            a = env.action_views
+        obs_n, rew_n, _, _ = env.step(a)
+        outs.append(torch.cat([o.clone() for o in obs_n], 1))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_scenario_callbacks_and_state_setters():
+    """The plug-in callbacks work stand-alone (make_env.py:40-43 wiring), entity.state setters feed
+    the kernels (KAT-1 / KAT-2 of SURVEY 8c through the public API)."""
+    from marl_amd import make_env
+    env = make_env('simple_tag', benchmark=True, num_envs=2)
+    env.reset()
+    w = env.world
+    far = [(5.0, 5.0), (-5.0, 5.0), (5.0, -5.0), (-5.0, -5.0)]
+    for i, e in enumerate(w.entities):
+        e.state.p_pos = np.array(far[i % 4]) * (1 + i)
+    w.agents[0].state.p_pos = np.array([0.0, 0.0])
+    w.agents[1].state.p_pos = np.array([0.1, 0.0])
+    env.step([np.zeros(5)] * 4)
+    np.testing.assert_allclose(_np(w.agents[0].state.p_vel), [[-0.5, 0.0]] * 2, atol=1e-12)
+    np.testing.assert_allclose(_np(w.agents[0].state.p_pos), [[-0.05, 0.0]] * 2, atol=1e-12)
+    assert (w.agents[1].state.p_vel.abs() < 1e-100).all()                 # one-sided (core.py:203-207)
+
+    env = make_env('simple_spread', benchmark=True, num_envs=3)
+    env.reset()
+    w = env.world
+    for i in range(3):
+        w.landmarks[i].state.p_pos = np.array([float(i), 0.0])
+        w.agents[i].state.p_pos = np.array([float(i), 0.0])
+    scen = env.reward_callback.__self__
+    for a in w.agents:
+        assert (scen.reward(a, w) == -1.0).all()                          # self-collision term
+        rew, coll, md, occ = scen.benchmark_data(a, w)
+        assert (coll == 1).all() and (occ == 3).all() and (md == 0).all()
+        assert scen.observation(a, w).shape == (3, 18)
+
+
+def test_user_scenario_callbacks_run_on_world_step():
+    """A scenario with its own torch callbacks (the reference's plug-in contract) still gets the
+    HIP World.step; obs/reward come from the callbacks as in environment.py:105-110."""
+    from marl_amd import make_env
+    from marl_amd.environment import MultiAgentEnv
+    base = make_env('simple_tag', num_envs=64, seed=2)
+    scen = base.reset_callback.__self__
+    w = base.world
+
+    def my_obs(agent, world):
+        return torch.cat([agent.state.p_vel, agent.state.p_pos], 1)
+
+    def my_rew(agent, world):
+        return -(agent.state.p_pos ** 2).sum(1)
+
+    env = MultiAgentEnv(w, scen.reset_world, my_rew, my_obs)
+    assert not env._fused and [s.shape[0] for s in env.observation_space] == [4] * 4
+    env.reset()
+    ref = make_env('simple_tag', num_envs=64, seed=2)
+    ref.world.episode = w.episode - 1
+    ref.reset()
+    assert torch.equal(ref.world.pos, w.pos)
+    act = torch.rand(64, 4, 5, device='cuda', dtype=torch.float64)
+    o1, r1, _, _ = env.step(act)
+    o2, r2, _, _ = ref.step(act)
+    assert torch.equal(ref.world.pos, w.pos) and torch.equal(ref.world.vel, w.vel)
+    for i in range(4):
+        assert torch.equal(o1[i], o2[i][:, :4])
+        assert torch.equal(r1[i], -(w.pos[i] ** 2).sum(0))
+
+
+def test_episode_stats_all_reduce_single_process():
+    from marl_amd import make_env
+    from marl_amd.distributed import EpisodeStats
+    env = make_env('simple_tag', benchmark=True, num_envs=2048, dtype=torch.float32, seed=4)
+    env.reset()
+    st = EpisodeStats(env.world)
+    tot_r = torch.zeros(4, dtype=torch.float64, device='cuda')
+    tot_c = torch.zeros(4, dtype=torch.float64, device='cuda')
+    for t in range(25):
+        _, rew_n, _, info_n = env.step(torch.softmax(torch.randn(2048, 4, 5, device='cuda'), -1))
+        tot_r += torch.stack(rew_n).double().sum(1)
+        tot_c += torch.stack(info_n['n']).double().sum(1)
+    s = st.summary(25)
+    assert s['env_steps'] == 25 * 2048 and s['episodes'] == 2048
+    np.testing.assert_allclose(s['mean_episode_reward'], (tot_r / 2048).cpu().numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(s['collisions_per_episode'], (tot_c / 2048).cpu().numpy(), rtol=1e-12)

@@ -1,0 +1,371 @@
+"""GPU parity tests (run on a real MI355X: pytest -m gpu).  Every test calls the HIP path through
+the C ABI of libmpe_hip.so and checks it against the committed golden vectors (generated from the
+reference) or against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  f64: |hip - reference| <= 1e-9 per step over whole 25-step episodes (free-running trajectories)
+  f32: <= 1e-4 relative (atol 1e-4 for quantities near zero); rewards / collision counts equal
+       except on envs within 1e-5 of a collision / bound() threshold.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tests.gpu_util import HipSim, dev, golden_soa, lib
+
+F64_TOL = 1e-9
+
+CASES = [
+    ('g1_simple_tag', lambda: O.simple_tag_spec()),
+    ('g2_simple_spread', lambda: O.simple_spread_spec()),
+    ('g3_scaled_tag', lambda: O.simple_tag_spec(48, 16, 32)),
+    ('g3d_scaled_tag_dense', lambda: O.simple_tag_spec(48, 16, 32)),
+    ('g4_simple_tag_unoise', lambda: O.simple_tag_spec(u_noise=0.3)),
+    ('g5_simple_tag_dense', lambda: O.simple_tag_spec()),
+    ('g5_simple_spread_dense', lambda: O.simple_spread_spec()),
+    ('g6_simple_tag_oob', lambda: O.simple_tag_spec()),
+]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+@pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
+def force_tile(request):
+    lib.mpe_debug_force_tile_kernel(request.param)
+    yield request.param
+    lib.mpe_debug_force_tile_kernel(0)
+
+
+def _maxerr(got, want):
+    return float(np.max(np.abs(got - want))) if got.size else 0.0
+
+
+@pytest.mark.parametrize('name,mk', CASES)
+def test_f64_trajectory_matches_reference(golden_dir, name, mk, force_tile):
+    """Free-running episodes from the golden initial state; compare every output of every step."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    sim = HipSim(spec, S, torch.float64)
+    sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'))
+    sim.observe(rew=False, info=False)
+    assert _maxerr(sim.host()[2], g['obs0'].T) == 0.0          # pure gathers/subtractions: exact
+    worst = 0.0
+    for t in range(T):
+        act = dev(golden_soa(g, 'act', t), torch.float64)
+        noise = dev(golden_soa(g, 'noise', t), torch.float64) if 'noise' in g.files else None
+        sim.env_step(act, noise)
+        pos, vel, obs, rew, info = sim.host()
+        errs = (_maxerr(pos, golden_soa(g, 'pos', t)), _maxerr(vel, golden_soa(g, 'vel', t)),
+                _maxerr(obs, g['obs'][:, t].T), _maxerr(rew, golden_soa(g, 'rew', t)),
+                _maxerr(info, golden_soa(g, 'info', t)))
+        worst = max(worst, *errs)
+        assert max(errs) <= F64_TOL, (name, t, errs)
+    print('%s force_tile=%d worst |err| = %.3e' % (name, force_tile, worst))
+
+
+@pytest.mark.parametrize('name,mk', CASES)
+def test_f32_teacher_forced_matches_reference(golden_dir, name, mk, force_tile):
+    """Each step starts from the golden state of the previous step (no error accumulation):
+    f32 outputs within 1e-4 relative of the float64 reference; discrete outputs equal except where
+    the reference itself is within 1e-5 of a threshold."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    sim = HipSim(spec, S, torch.float32)
+    A = spec.n_agents
+    for t in range(T):
+        p0 = golden_soa(g, 'pos0') if t == 0 else golden_soa(g, 'pos', t - 1)
+        v0 = golden_soa(g, 'vel0') if t == 0 else golden_soa(g, 'vel', t - 1)
+        sim.set_state(p0, v0)
+        act = dev(golden_soa(g, 'act', t), torch.float32)
+        noise = dev(golden_soa(g, 'noise', t), torch.float32) if 'noise' in g.files else None
+        sim.env_step(act, noise)
+        pos, vel, obs, rew, info = sim.host()
+        np.testing.assert_allclose(pos, golden_soa(g, 'pos', t), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(vel, golden_soa(g, 'vel', t), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(obs, g['obs'][:, t].T, rtol=1e-4, atol=1e-4)
+        # discrete parts: flag envs where any pair distance / |pos| is near a threshold
+        P = golden_soa(g, 'pos', t)                                   # [E,2,S]
+        dist = np.sqrt(((P[:A, None] - P[None, :A]) ** 2).sum(2))      # [A,A,S]
+        dmin = np.add.outer(np.asarray(spec.size[:A]), np.asarray(spec.size[:A]))[..., None]
+        near = (np.abs(dist - dmin) < 1e-5).any((0, 1))
+        if spec.kind == O.SIMPLE_TAG:
+            ax = np.abs(P[:A])
+            near |= (np.abs(ax - 0.9) < 1e-5).any((0, 1)) | (np.abs(ax - 1.0) < 1e-5).any((0, 1))
+        else:
+            dl = np.sqrt(((P[:A, None] - P[None, A:]) ** 2).sum(2))
+            near |= (np.abs(dl - 0.1) < 1e-5).any((0, 1))
+        ok = ~near
+        np.testing.assert_allclose(rew[:, ok], golden_soa(g, 'rew', t)[:, ok], rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(info[..., ok], golden_soa(g, 'info', t)[..., ok], rtol=1e-4, atol=2e-4)
+        assert ok.mean() > 0.9
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec(),
+                                lambda: O.simple_tag_spec(5, 3, 4), lambda: O.simple_spread_spec(5, 7)],
+                         ids=['tag', 'spread', 'tag_5_3_4', 'spread_5_7'])
+def test_split_entry_points_equal_fused(mk, dtype, force_tile):
+    """mpe_world_step + mpe_observe == mpe_env_step, bit for bit; ragged batch (B not a tile multiple)
+    inside a larger allocation (ld > B): rows beyond B must stay untouched."""
+    spec = mk()
+    B, ld = 1000 + 37, 1200
+    rng = np.random.RandomState(1)
+    pos = rng.uniform(-0.5, 0.5, (spec.n_entities, 2, B))
+    vel = rng.uniform(-0.5, 0.5, (spec.n_agents, 2, B))
+    act = torch.zeros(spec.n_agents, 5, ld, dtype=dtype, device='cuda')
+    act[:, :, :B] = dev(rng.rand(spec.n_agents, 5, B), dtype)
+    a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
+    a.set_state(pos, vel)
+    b.set_state(pos, vel)
+    comm = torch.full((spec.n_agents, spec.dim_c, ld), 7.0, dtype=dtype, device='cuda')
+    for _ in range(3):
+        a.env_step(act)
+        b.world_step(act, comm=comm)
+        b.observe()
+    for x, y in zip(a.host(), b.host()):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert (comm[:, :, :B] == 0).all() and (comm[:, :, B:] == 7).all()     # core.py:226-227
+    for t in (a.obs, a.rew, a.info):
+        assert torch.isnan(t[..., B:]).all()                               # padding never written
+    assert (a.pos[..., B:] == 0).all() and (a.vel[..., B:] == 0).all()
+
+
+@pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec()], ids=['tag', 'spread'])
+def test_small_and_tile_kernels_bit_identical(mk):
+    """The register kernel and the LDS-tile kernel implement the same operation order."""
+    spec = mk()
+    B = 4096 + 11
+    rng = np.random.RandomState(2)
+    pos = rng.uniform(-0.4, 0.4, (spec.n_entities, 2, B))
+    vel = rng.uniform(-1, 1, (spec.n_agents, 2, B))
+    for dtype in (torch.float64, torch.float32):
+        act = dev(rng.rand(spec.n_agents, 5, B), dtype)
+        res = []
+        for ft in (0, 1):
+            lib.mpe_debug_force_tile_kernel(ft)
+            sim = HipSim(spec, B, dtype)
+            sim.set_state(pos, vel)
+            for _ in range(5):
+                sim.env_step(act)
+            res.append(sim.host())
+        lib.mpe_debug_force_tile_kernel(0)
+        for x, y in zip(*res):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_config2_simple_spread_65536_f64_vs_oracle():
+    """BASELINE config 2: simple_spread N=3, 65,536 envs, fp64, 25-step episode, every output of
+    every step within 1e-9 of the CPU oracle fed the same initial state and actions."""
+    spec = O.simple_spread_spec()
+    B, T = 65536, 25
+    rng = np.random.RandomState(3)
+    pos = rng.uniform(-1, 1, (6, 2, B))
+    vel = np.zeros((3, 2, B))
+    bo = O.BatchedOracle(spec)
+    sim = HipSim(spec, B, torch.float64)
+    sim.set_state(pos, vel)
+    worst = 0.0
+    for t in range(T):
+        logits = rng.randn(3, 5, B)
+        act = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act)
+        sim.env_step(dev(act, torch.float64))
+        hp, hv, ho, hr, hi = sim.host()
+        errs = (_maxerr(hp, pos), _maxerr(hv, vel), _maxerr(ho, np.concatenate(obs, 0)), _maxerr(hr, rew),
+                _maxerr(hi, info))
+        worst = max(worst, *errs)
+        assert max(errs) <= F64_TOL, (t, errs)
+    print('config2 worst |err| = %.3e' % worst)
+
+
+def test_config3_simple_tag_1M_f32_properties():
+    """BASELINE config 3 size (1,048,576 envs, f32): a 4,096-env sample against the oracle (1e-4),
+    plus size-independent properties on the full batch: run-to-run determinism, adversary reward ==
+    10 * sum of adversary collision counts, observation rows consistent with the state."""
+    spec = O.simple_tag_spec()
+    B, T = 1 << 20, 25
+    g = torch.Generator(device='cuda').manual_seed(5)
+    pos0 = torch.rand(6, 2, B, generator=g, device='cuda') * 1.2 - 0.6
+    vel0 = torch.zeros(4, 2, B, device='cuda')
+    acts = [torch.softmax(torch.randn(4, 5, B, generator=g, device='cuda'), dim=1) for _ in range(T)]
+    runs = []
+    for rep in range(2):
+        sim = HipSim(spec, B, torch.float32)
+        sim.pos.copy_(pos0)
+        sim.vel.copy_(vel0)
+        for t in range(T):
+            sim.env_step(acts[t])
+        runs.append(sim)
+    a, b = runs
+    for x, y in ((a.pos, b.pos), (a.vel, b.vel), (a.obs, b.obs), (a.rew, b.rew), (a.info, b.info)):
+        assert torch.equal(x, y)
+    assert torch.isfinite(a.obs).all() and torch.isfinite(a.rew).all()
+    # reward / info consistency (simple_tag.py:57-66,115-129)
+    assert torch.equal(a.rew[0], 10 * a.info[:3, 0].sum(0)) and torch.equal(a.rew[0], a.rew[1])
+    assert (a.info[3] == 0).all() and (a.info[:3].sum() > 0)
+    # obs rows vs state (simple_tag.py:131-147): agent 3 (good): [vel, pos, lm-pos x2, others-pos x3]
+    o3 = a.obs[48:62]
+    assert torch.equal(o3[0:2], a.vel[3]) and torch.equal(o3[2:4], a.pos[3])
+    assert torch.equal(o3[4:6], a.pos[4] - a.pos[3]) and torch.equal(o3[8:10], a.pos[0] - a.pos[3])
+    assert torch.equal(a.obs[14:16], a.vel[3])                          # adversary 0 sees the prey's velocity
+    # sample vs oracle (f64 oracle on the f32 inputs), free-running 25 steps
+    idx = torch.arange(0, B, B // 4096, device='cuda')[:4096]
+    bo = O.BatchedOracle(spec)
+    p, v = pos0[:, :, idx].double().cpu().numpy(), vel0[:, :, idx].double().cpu().numpy()
+    for t in range(T):
+        p, v, obs, rew, info = bo.env_step(p, v, acts[t][:, :, idx].double().cpu().numpy())
+    hp = a.pos[:, :, idx].double().cpu().numpy()
+    hv = a.vel[:, :, idx].double().cpu().numpy()
+    # chaotic contacts amplify f32 rounding over 25 free-running steps: compare the bulk tightly and
+    # allow a small fraction of envs (those that went through a hard contact) a looser bound
+    err = np.maximum(np.abs(hp - p).max((0, 1)), np.abs(hv - v).max((0, 1)))
+    assert np.mean(err < 1e-4) > 0.97, np.mean(err < 1e-4)
+    assert np.median(err) < 5e-6
+
+
+def test_config5_scaled_tag_f64_and_f32_vs_oracle():
+    """BASELINE config 5 shape (48 adversaries, 16 good, 32 landmarks): f64 spot check on 256 envs
+    vs the oracle (1e-9), f32 teacher-forced (1e-4), dense starts so contacts fire."""
+    spec = O.simple_tag_spec(48, 16, 32)
+    B = 256 + 3
+    rng = np.random.RandomState(7)
+    pos = rng.uniform(-1.0, 1.0, (96, 2, B))
+    vel = rng.uniform(-0.3, 0.3, (64, 2, B))
+    bo = O.BatchedOracle(spec)
+    s64, s32 = HipSim(spec, B, torch.float64), HipSim(spec, B, torch.float32)
+    s64.set_state(pos, vel)
+    for t in range(4):
+        act = rng.rand(64, 5, B)
+        s32.set_state(pos, vel)
+        s32.env_step(dev(act, torch.float32))
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act)
+        s64.env_step(dev(act, torch.float64))
+        hp, hv, ho, hr, hi = s64.host()
+        errs = (_maxerr(hp, pos), _maxerr(hv, vel), _maxerr(ho, np.concatenate(obs, 0)), _maxerr(hr, rew),
+                _maxerr(hi, info))
+        assert max(errs) <= F64_TOL, (t, errs)
+        fp, fv, fo, fr, fi = s32.host()
+        np.testing.assert_allclose(fp, pos, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(fv, vel, rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(fo, np.concatenate(obs, 0), rtol=1e-4, atol=2e-4)
+        assert np.mean(fr == rew) > 0.98 and np.mean(fi == info) > 0.98
+    assert (rew[:48] > 0).any() and (rew[48:] <= -10).any()
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+def test_reset_matches_philox_oracle(dtype, force_tile):
+    """mpe_reset_* draws exactly the oracle's Philox stream; masked envs untouched; the result does
+    not depend on how envs are split into calls (env_id0)."""
+    spec = O.simple_tag_spec()
+    B = 5000
+    sim = HipSim(spec, B, dtype)
+    sim.vel.fill_(3.0)
+    sim.reset(seed=0x1234567890ABCDEF, episode=7)
+    want = O.reset_positions(spec, 0x1234567890ABCDEF, 7, np.arange(B, dtype=np.uint64),
+                             np.float64 if dtype == torch.float64 else np.float32)
+    assert np.array_equal(sim.pos.cpu().numpy(), want)
+    assert (sim.vel == 0).all()
+    # shard independence
+    lo = HipSim(spec, 2000, dtype)
+    lo.reset(seed=0x1234567890ABCDEF, episode=7, env_id0=3000)
+    assert torch.equal(lo.pos, sim.pos[:, :, 3000:5000])
+    big = HipSim(spec, 16, dtype)
+    big.reset(seed=1, episode=0, env_id0=(1 << 40) + 5)
+    want = O.reset_positions(spec, 1, 0, np.arange(16, dtype=np.uint64) + np.uint64((1 << 40) + 5),
+                             np.float64 if dtype == torch.float64 else np.float32)
+    assert np.array_equal(big.pos.cpu().numpy(), want)
+    # mask
+    before = sim.pos.clone()
+    mask = (torch.arange(B, device='cuda') % 3 == 0).to(torch.uint8)
+    sim.vel.fill_(1.0)
+    sim.reset(seed=5, episode=8, mask=mask)
+    m = mask.bool()
+    assert torch.equal(sim.pos[:, :, ~m], before[:, :, ~m]) and not torch.equal(sim.pos[:, :, m], before[:, :, m])
+    assert (sim.vel[:, :, m] == 0).all() and (sim.vel[:, :, ~m] == 1).all()
+
+
+@pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec(),
+                                lambda: O.simple_tag_spec(6, 2, 3)], ids=['tag', 'spread', 'tag_6_2_3'])
+def test_episode_stats_rows_and_reduce(mk, force_tile):
+    """Per-workgroup statistics rows + deterministic reduce == sums of the per-env outputs."""
+    spec = mk()
+    A = spec.n_agents
+    B = 3000 + 13
+    rng = np.random.RandomState(11)
+    sim = HipSim(spec, B, torch.float32)
+    sim.set_state(rng.uniform(-0.3, 0.3, (spec.n_entities, 2, B)), np.zeros((A, 2, B)))
+    rows = lib.mpe_stats_rows(sim.desc, B, 4)
+    W = lib.mpe_stats_width(sim.desc)
+    assert W == 2 * A + 2 and rows >= 1
+    stats = torch.zeros(rows, W, dtype=torch.float64, device='cuda')
+    want = torch.zeros(W, dtype=torch.float64, device='cuda')
+    for t in range(6):
+        sim.env_step(dev(rng.rand(A, 5, B), torch.float32), stats=stats)
+        want[:A] += sim.rew[:, :B].double().sum(1)
+        col = 0 if spec.kind == O.SIMPLE_TAG else 1
+        want[A:2 * A] += sim.info[:, col, :B].double().sum(1)
+        if spec.kind == O.SIMPLE_TAG:
+            want[2 * A] += sim.info[:, 0, :B].double().sum()
+        else:
+            want[2 * A] += sim.info[0, 3, :B].double().sum()
+        want[2 * A + 1] += B
+    out = torch.empty(W, dtype=torch.float64, device='cuda')
+    assert lib.mpe_stats_reduce(stats.data_ptr(), rows, W, out.data_ptr(), sim.stream) == 0
+    torch.testing.assert_close(out, want, rtol=1e-12, atol=1e-9)
+    out2 = torch.empty_like(out)
+    lib.mpe_stats_reduce(stats.data_ptr(), rows, W, out2.data_ptr(), sim.stream)
+    assert torch.equal(out, out2)
+    assert out[2 * A + 1].item() == 6 * B and out[A:2 * A].sum().item() > 0
+
+
+def test_coincident_entities_give_nan_like_the_reference():
+    """dist == 0 -> delta/dist = NaN in the reference (core.py:246); parity means not 'fixing' it."""
+    spec = O.simple_tag_spec()
+    pos = np.zeros((6, 2, 2))
+    pos[:, 0, :] = np.arange(6)[:, None] * 1.0
+    pos[1, :, 0] = pos[0, :, 0]                 # env 0: agents 0 and 1 coincide
+    sim = HipSim(spec, 2, torch.float64)
+    sim.set_state(pos, np.zeros((4, 2, 2)))
+    sim.env_step(dev(np.zeros((4, 5, 2)), torch.float64))
+    p, v = O.BatchedOracle(spec).world_step(pos, np.zeros((4, 2, 2)), np.zeros((4, 5, 2)))
+    hp, hv = sim.host()[:2]
+    assert np.isnan(p[0, :, 0]).all() and np.isnan(hp[0, :, 0]).all()
+    assert np.array_equal(np.isnan(hp), np.isnan(p)) and np.array_equal(np.isnan(hv), np.isnan(v))
+
+
+def test_c_abi_rejects_bad_arguments():
+    spec = O.simple_tag_spec()
+    sim = HipSim(spec, 8, torch.float64)
+    act = torch.zeros(4, 5, 8, dtype=torch.float64, device='cuda')
+    f = lib.mpe_env_step_f64
+    args = [sim.desc, 8, 8, act.data_ptr(), None, sim.pos.data_ptr(), sim.vel.data_ptr(), None,
+            sim.obs.data_ptr(), sim.rew.data_ptr(), sim.info.data_ptr(), None, sim.stream]
+    assert f(*args) == 0
+    bad = list(args); bad[1] = 0
+    assert f(*bad) == -3
+    bad = list(args); bad[2] = 4
+    assert f(*bad) == -3
+    bad = list(args); bad[3] = None
+    assert f(*bad) == -1
+    bad = list(args); bad[5] = sim.pos.data_ptr() + 4
+    assert f(*bad) == -4
+    d = type(sim.desc).from_buffer_copy(sim.desc)
+    d.n_agents = 100
+    bad = list(args); bad[0] = d
+    assert f(*bad) == -2
+    d = type(sim.desc).from_buffer_copy(sim.desc)
+    d.movable[5] = 1
+    bad = list(args); bad[0] = d
+    assert f(*bad) == -5
+    torch.cuda.synchronize()
