@@ -259,7 +259,9 @@ def test_config5_scaled_tag_f64_and_f32_vs_oracle():
         np.testing.assert_allclose(fp, pos, rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(fv, vel, rtol=1e-4, atol=2e-4)
         np.testing.assert_allclose(fo, np.concatenate(obs, 0), rtol=1e-4, atol=2e-4)
-        assert np.mean(fr == rew) > 0.98 and np.mean(fi == info) > 0.98
+        # 768 (good, adversary) pairs per env: an f32 flip of one strict '<' moves a count by 1, so
+        # compare per element and allow the few near-threshold envs
+        assert np.mean(np.abs(fr - rew) <= 1e-3) > 0.98 and np.mean(fi == info) > 0.98
     assert (rew[:48] > 0).any() and (rew[48:] <= -10).any()
 
 
