@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: agent-steps/sec of batched simple_tag on N MI355X (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one MultiAgentEnv.step() over the rank's whole batch (action decode + World.step +
+observation + reward + benchmark info for all agents, one fused HIP launch), with the periodic
+Scenario.reset_world + observation gather every 25 steps inside the timed region, episode
+statistics accumulated on device and all-reduced (RCCL) once per episode.  Inputs (state, a
+rotating pool of action tensors) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, fused
+env-step kernel, HIP-event timed per launch inside the timed region) and `cpu_baseline` (the
+oracle's serial numpy loop on one host core, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md, Chip-level parameters)
+EPISODE_LEN = 25
+
+WORKLOADS = {
+    # name: (scenario, scenario kwargs, envs per GPU, dtype)
+    'simple_tag_1M_f32': ('simple_tag', {}, 1 << 20, torch.float32),            # BASELINE configs[2]/[3]
+    'simple_spread_64k_f64': ('simple_spread', {}, 1 << 16, torch.float64),     # BASELINE configs[1]
+    'scaled_tag_256k_f32': ('simple_tag', dict(num_adversaries=48, num_good_agents=16, num_landmarks=32),
+                            1 << 18, torch.float32),                              # BASELINE configs[4]
+    'simple_tag_1M_f64': ('simple_tag', {}, 1 << 20, torch.float64),
+}
+
+
+def algorithmic_elems(env, with_info=True):
+    """compulsory elements moved per env-step:
+    5A act + 2E pos rd + 2A vel rd + 4A pos,vel wr + sum obs_dim + A reward + A*info_w."""
+    w = env.world
+    A, E = len(w.agents), len(w.entities)
+    obs = sum(s.shape[0] for s in env.observation_space)
+    info_w = w.info.shape[1] if (with_info and w.info is not None) else 0
+    return 5 * A + 2 * E + 2 * A + 4 * A + obs + A + A * info_w
+
+
+def cpu_baseline(seconds=12.0):
+    """Reference's serial numpy loop, restated (oracle.SerialEnv: one Python object per entity,
+    validated bit-exact against the reference), on ONE host core: simple_tag, 25-step episodes
+    incl. reset, random soft actions, benchmark=True -- the configuration of BASELINE.md."""
+    import numpy as np
+    from oracle import mpe_oracle as O
+    spec = O.simple_tag_spec()
+    env = O.SerialEnv(spec, benchmark=True)
+    rng = np.random.RandomState(0)
+    np.random.seed(0)
+    env.reset()
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(EPISODE_LEN):
+            env.step([rng.rand(5) for _ in range(env.n)])
+        env.reset()
+        steps += EPISODE_LEN
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {'value': steps * env.n / dt, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d env-steps of simple_tag (A=4, L=2), 25-step episodes incl. reset, benchmark=True, '
+                      'serial numpy loop (oracle.SerialEnv) on 1 host core of %d' % (steps, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--workload', default='simple_tag_1M_f32', choices=sorted(WORKLOADS))
+    ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (roofline from wall time)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world_size = int(os.environ.get('WORLD_SIZE', 1))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world_size
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world_size > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    from marl_amd import make_env
+    from marl_amd.distributed import EpisodeStats, shard_range, summarize_stats
+
+    scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[args.workload]
+    B = args.envs or envs_per_gpu
+    env_id0, _ = shard_range(B * world_size, rank, world_size)      # weak scaling: B per GPU fixed
+    env = make_env(scenario, benchmark=True, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
+    env.world.env_id0 = env_id0
+    n = env.n
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    pool = [torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1).contiguous()
+            for _ in range(4)]
+    stats = EpisodeStats(env.world)
+    stats_total = torch.zeros(2 * n + 2, dtype=torch.float64, device=device)
+
+    def run(nsteps, events=None, t_base=0):
+        for t in range(nsteps):
+            tt = t_base + t
+            if tt % EPISODE_LEN == 0:
+                if tt:
+                    stats_total.add_(stats.read())      # deterministic reduce + one all-reduce / episode
+                    stats.reset()
+                env.reset()
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                env.step(pool[tt & 3])
+                e1.record()
+                events.append((e0, e1))
+            else:
+                env.step(pool[tt & 3])
+
+    def fence():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    events = None if args.no_events else []
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, events, t_base=args.warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    stats_total.add_(stats.read())
+
+    elems = algorithmic_elems(env)
+    bytes_per_launch = elems * env.world.pos.element_size() * B
+    if events:
+        ms = sorted(a.elapsed_time(b) for a, b in events)
+        kern_ms = sum(ms) / len(ms)
+        kern_med = ms[len(ms) // 2]
+    else:
+        kern_ms = kern_med = elapsed * 1e3 / args.steps
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        value = B * world_size * n * args.steps / elapsed
+        out = {
+            'metric': 'agent-steps/sec (whole node) for batched simple_tag' if scenario == 'simple_tag' and not kwargs
+                      else 'agent-steps/sec (whole node), %s' % args.workload,
+            'value': value, 'unit': 'agent-steps/s', 'n_gpus': world_size, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if dtype == torch.float32 else 'f64', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'scenario': scenario, 'envs_per_gpu': B,
+                       'agents': n, 'entities': len(env.world.entities), 'episode_len': EPISODE_LEN,
+                       'actions': 'softmax(N(0,1)) soft one-hot, 4 resident buffers rotated',
+                       'reset_in_timed_region': True, 'benchmark_info': True,
+                       'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
+                       'parallelism': 'env-sharded dp%d' % world_size},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'mpe env_step (fused)', 'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'bytes_per_env_step': elems * env.world.pos.element_size(),
+                         'avg_launch_ms': kern_ms, 'median_launch_ms': kern_med,
+                         'timing': 'hip events per launch' if events else 'wall/steps'},
+            'episode_stats': summarize_stats(stats_total, n, EPISODE_LEN),
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

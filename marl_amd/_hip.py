@@ -7,6 +7,11 @@ fallback: if the shared library is missing, importing this module raises.
 import ctypes as C
 import os
 
+# torch must be loaded BEFORE libmpe_hip.so: both need libamdhip64.so.7 and the process must end up
+# with the HIP runtime that torch ships (streams / device pointers are shared with torch); loading
+# this library first would bind the system runtime instead and torch would find no device.
+import torch  # noqa: F401
+
 MPE_MAX_AGENTS = 64
 MPE_MAX_ENTITIES = 128
 MPE_SIMPLE_TAG = 0
@@ -91,7 +96,6 @@ def check(code, where):
 
 
 def suffix(dtype):
-    import torch
     if dtype == torch.float32:
         return 'f32'
     if dtype == torch.float64:
@@ -105,5 +109,4 @@ def ptr(t):
 
 
 def stream_of(device):
-    import torch
     return torch.cuda.current_stream(device).cuda_stream

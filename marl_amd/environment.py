@@ -5,8 +5,8 @@
     obs_n = env.reset()                       # list of n tensors [B, obs_dim_i]
     obs_n, reward_n, done_n, info_n = env.step(action_n)
 
-``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190) or
-one tensor ``[B, n, 5]``.  Policies can write straight into ``env.action_views[i]`` (``[B,5]``
+``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190), one
+tensor ``[B, n, 5]``, or one contiguous tensor ``[n, 5, B]`` (the kernel's SoA layout, used in place).  Policies can write straight into ``env.action_views[i]`` (``[B,5]``
 views of the kernel's SoA action buffer) and pass that list: then step() copies nothing.
 Returned tensors are views of buffers that the next step()/reset() overwrites.
 
@@ -64,6 +64,7 @@ class MultiAgentEnv(object):
             self.action_space.append(spaces.Discrete(world.dim_p * 2 + 1))
             obs_dim = int(observation_callback(agent, self.world).shape[-1])
             self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf, shape=(obs_dim,), dtype=np.float32))
+        self._own_act = world.act
         self.action_views = [world.act[i].t() for i in range(self.n)]      # [B,5] views, strides (1,B)
         self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=world.device)
         self._empty_info = [{} for _ in range(self.n)]
@@ -71,6 +72,15 @@ class MultiAgentEnv(object):
     # -- environment.py:157-208: the decode itself runs inside the kernel ------------------------------
     def _set_actions(self, action_n):
         act = self.world.act
+        if torch.is_tensor(action_n) and action_n.dim() == 3 and action_n.is_contiguous() \
+                and tuple(action_n.shape) == tuple(act.shape) and action_n.dtype == act.dtype \
+                and action_n.device == act.device and (self.num_envs, self.n) != (5, 5):
+            # SoA fast path: a contiguous [n, 5, B] tensor is the kernel's own layout; adopt it in
+            # place (no copy).  env.action_views keep pointing at the env's original buffer.
+            self.world.act = action_n
+            return
+        if act.data_ptr() != self._own_act.data_ptr():
+            self.world.act = act = self._own_act
         if torch.is_tensor(action_n) and action_n.dim() == 3:
             if tuple(action_n.shape) != (self.num_envs, self.n, 5):
                 raise ValueError('action tensor must be [num_envs, n, 5]')
