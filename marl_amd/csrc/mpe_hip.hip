@@ -109,6 +109,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
   d.damp1 = (T)(1 - h->damping);  // core.py:214: (1 - self.damping) evaluated in float64
   d.cforce = (T)h->contact_force;
   d.k = (T)h->contact_margin;
+  d.inv_k = (T)(1.0 / h->contact_margin);
   int row = 0;
   for (int e = 0; e < d.E; ++e) {
     d.size[e] = (T)h->size[e];
@@ -135,12 +136,19 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
 // ------------------------------------------------------------------------------------------------
 enum SmallId { SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3 };
 
+// The register kernel hard-codes the stock role flags (mpe_small_kernel.h); anything else -> tile kernel.
 static SmallId small_variant(const mpe_scenario_desc *h) {
-  if (h->kind == MPE_SIMPLE_TAG && h->n_agents == 4 && h->n_landmarks == 2 && h->adversary[0] &&
-      h->adversary[1] && h->adversary[2] && !h->adversary[3])
-    return SMALL_TAG_3_1_2;
-  if (h->kind == MPE_SIMPLE_SPREAD && h->n_agents == 3 && h->n_landmarks == 3) return SMALL_SPREAD_3_3;
-  return SMALL_NONE;
+  const int A = h->n_agents, L = h->n_landmarks;
+  const bool tag = h->kind == MPE_SIMPLE_TAG;
+  if (!((tag && A == 4 && L == 2) || (!tag && A == 3 && L == 3))) return SMALL_NONE;
+  for (int a = 0; a < A; ++a) {
+    if (!h->movable[a] || !h->collide[a]) return SMALL_NONE;
+    if (tag ? !(h->max_speed[a] >= 0.0) : (h->max_speed[a] >= 0.0)) return SMALL_NONE;
+    if (tag && (h->adversary[a] != 0) != (a < 3)) return SMALL_NONE;
+  }
+  for (int e = A; e < A + L; ++e)
+    if ((h->collide[e] != 0) != tag) return SMALL_NONE;
+  return tag ? SMALL_TAG_3_1_2 : SMALL_SPREAD_3_3;
 }
 
 static bool g_force_tile = false;  // test hook: route the stock worlds through the tile kernel too
@@ -151,10 +159,20 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s
   const SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
   if (sv != SMALL_NONE) {
     const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-    if (sv == SMALL_TAG_3_1_2)
-      hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-    else
-      hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_SPREAD, 3, 3, 0, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+    bool noise = false;
+    if (DO_STEP && p.noise != nullptr)
+      for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
+    if (sv == SMALL_TAG_3_1_2) {
+      if (noise)
+        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      else
+        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+    } else {
+      if (noise)
+        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_SPREAD, 3, 3, 0, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      else
+        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_SPREAD, 3, 3, 0, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+    }
     return (int)hipGetLastError();
   }
   constexpr int TILE = tile_envs<T>();

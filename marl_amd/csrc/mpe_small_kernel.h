@@ -1,9 +1,23 @@
 // Register-resident env-step kernel for the stock small worlds (simple_tag 3+1 agents / 2
-// landmarks, simple_spread 3 / 3): one env per lane, entity counts are template constants so the
-// whole state (E positions, A velocities) lives in VGPRs and every loop is fully unrolled.
+// landmarks, simple_spread 3 / 3): one env per lane, entity counts and the stock role flags are
+// template constants, so the whole state (E positions, A velocities) lives in VGPRs, every loop is
+// fully unrolled and the kernel is straight-line code:
+//
+//     issue ALL loads (36 rows) -> one wait -> ~700 VALU ops -> 86 streaming stores
+//
 // A wavefront = 64 consecutive envs, so each load/store instruction moves one contiguous
-// 64*sizeof(T)-byte segment of an SoA row.  simple_tag requires the stock role order: the first
-// NADV agents are the adversaries (simple_tag.py:21).
+// 64*sizeof(T)-byte segment of an SoA row; row bases are wave-uniform (SGPR) and the lane offset
+// is a 32-bit VGPR, so address arithmetic is almost free.
+//
+// "Stock flags" (checked on the host, mpe_hip.hip:small_variant): every agent movable and
+// colliding; landmarks collide in simple_tag and do not in simple_spread; simple_tag agents all
+// have a max_speed and the first NADV agents are the adversaries (simple_tag.py:16-33);
+// simple_spread agents have none (simple_spread.py:15-25).  Sizes, accel, mass, dt, damping and
+// the contact constants stay run-time values.  Anything else runs the LDS-tile kernel.
+//
+// Cache policy: actions / noise are read once (nontemporal loads) and observations / rewards / info
+// are written once (nontemporal stores); pos / vel use the default policy so the env state, which
+// is re-read every step, can stay in L2 / Infinity Cache.
 #pragma once
 #include "mpe_device.h"
 
@@ -11,66 +25,80 @@ namespace mpe {
 
 constexpr int kSmallThreads = 256;
 
-template <typename T, int KIND, int A, int L, int NADV, bool DO_STEP, bool DO_OBS>
+template <typename T, int KIND, int A, int L, int NADV, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
 __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
+  constexpr bool TAG = KIND == MPE_SIMPLE_TAG;
+  constexpr int ECOL = TAG ? E : A;  // entities that collide (stock flags)
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t env0 = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
-  const bool active = env0 < p.B;
-  const int64_t env = active ? env0 : p.B - 1;  // tail lanes shadow the last env and never store
+  const int64_t blk0 = (int64_t)blockIdx.x * kSmallThreads;  // wave-uniform
+  const bool active = blk0 + threadIdx.x < p.B;
+  // tail lanes shadow the last env (loads stay in bounds) and never store
+  const uint32_t lo = active ? threadIdx.x : (uint32_t)(p.B - 1 - blk0);
 
+  const T *gpos = p.pos + blk0, *gvel = p.vel + blk0;
   T px[E], py[E], vx[A], vy[A];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    px[e] = p.pos[(int64_t)(2 * e) * ld + env];
-    py[e] = p.pos[(int64_t)(2 * e + 1) * ld + env];
+    px[e] = (gpos + (int64_t)(2 * e) * ld)[lo];
+    py[e] = (gpos + (int64_t)(2 * e + 1) * ld)[lo];
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = p.vel[(int64_t)(2 * a) * ld + env];
-    vy[a] = p.vel[(int64_t)(2 * a + 1) * ld + env];
+    vx[a] = (gvel + (int64_t)(2 * a) * ld)[lo];
+    vy[a] = (gvel + (int64_t)(2 * a + 1) * ld)[lo];
   }
 
   if (DO_STEP) {
+    const T *gact = p.act + blk0;
+    T a1[A], a2[A], a3[A], a4[A], nx[A], ny[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {  // a[0] (the no-op slot) is never read (environment.py:189-190)
+      a1[a] = ld_stream(gact + (int64_t)(5 * a + 1) * ld + lo);
+      a2[a] = ld_stream(gact + (int64_t)(5 * a + 2) * ld + lo);
+      a3[a] = ld_stream(gact + (int64_t)(5 * a + 3) * ld + lo);
+      a4[a] = ld_stream(gact + (int64_t)(5 * a + 4) * ld + lo);
+      if (HAS_NOISE) {
+        nx[a] = ld_stream(p.noise + blk0 + (int64_t)(2 * a) * ld + lo);
+        ny[a] = ld_stream(p.noise + blk0 + (int64_t)(2 * a + 1) * ld + lo);
+      }
+    }
     T Fx[A], Fy[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // environment.py:188-196, core.py:147-148
-      const T *ar = p.act + (int64_t)(5 * a) * ld + env;
-      Fx[a] = (ar[1 * ld] - ar[2 * ld]) * d.accel[a];
-      Fy[a] = (ar[3 * ld] - ar[4 * ld]) * d.accel[a];
-      if (p.noise != nullptr && d.u_noise[a] != T(0)) {
-        Fx[a] = Fx[a] + p.noise[(int64_t)(2 * a) * ld + env] * d.u_noise[a];
-        Fy[a] = Fy[a] + p.noise[(int64_t)(2 * a + 1) * ld + env] * d.u_noise[a];
+      Fx[a] = (a1[a] - a2[a]) * d.accel[a];
+      Fy[a] = (a3[a] - a4[a]) * d.accel[a];
+      if (HAS_NOISE) {  // u_noise[a] == 0 encodes None: u + 0.0*n would differ only for n = inf/nan
+        Fx[a] = d.u_noise[a] != T(0) ? Fx[a] + nx[a] * d.u_noise[a] : Fx[a];
+        Fy[a] = d.u_noise[a] != T(0) ? Fy[a] + ny[a] * d.u_noise[a] : Fy[a];
       }
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:199-205, b ascending; only a is pushed
-      if (!(bit(d.collide, a) && bit(d.movable, a))) continue;
 #pragma unroll
-      for (int b = a + 1; b < E; ++b) {
-        if (!bit(d.collide, b)) continue;
+      for (int b = a + 1; b < ECOL; ++b) {
         T fx, fy;
-        pair_force<T>(px[a] - px[b], py[a] - py[b], d.size[a] + d.size[b], d.k, d.cforce, fx, fy);
+        pair_force<T>(px[a] - px[b], py[a] - py[b], d.size[a] + d.size[b], d, fx, fy);
         Fx[a] = fx + Fx[a];
         Fy[a] = fy + Fy[a];
       }
     }
+    T *spos = p.pos + blk0, *svel = p.vel + blk0;
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:211-222
-      if (!bit(d.movable, a)) continue;
-      integrate_vel<T>(vx[a], vy[a], Fx[a], Fy[a], d.mass[a], d.damp1, d.dt, d.max_speed[a]);
+      integrate_vel_sel<T, TAG>(vx[a], vy[a], Fx[a], Fy[a], d.mass[a], d.damp1, d.dt, d.max_speed[a]);
       px[a] = px[a] + vx[a] * d.dt;
       py[a] = py[a] + vy[a] * d.dt;
       if (active) {
-        p.vel[(int64_t)(2 * a) * ld + env] = vx[a];
-        p.vel[(int64_t)(2 * a + 1) * ld + env] = vy[a];
-        p.pos[(int64_t)(2 * a) * ld + env] = px[a];
-        p.pos[(int64_t)(2 * a + 1) * ld + env] = py[a];
+        (svel + (int64_t)(2 * a) * ld)[lo] = vx[a];
+        (svel + (int64_t)(2 * a + 1) * ld)[lo] = vy[a];
+        (spos + (int64_t)(2 * a) * ld)[lo] = px[a];
+        (spos + (int64_t)(2 * a + 1) * ld)[lo] = py[a];
       }
     }
     if (p.comm != nullptr && active)  // core.py:226-227
-      for (int r = 0; r < A * d.dim_c; ++r) p.comm[(int64_t)r * ld + env] = T(0);
+      for (int r = 0; r < A * d.dim_c; ++r) (p.comm + blk0 + (int64_t)r * ld)[lo] = T(0);
   }
 
   if (DO_OBS) {
@@ -78,32 +106,32 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
     if (p.obs != nullptr && active) {
 #pragma unroll
       for (int i = 0; i < A; ++i) {
-        T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
+        T *o = p.obs + blk0 + (int64_t)d.obs_row0[i] * ld;
         int r = 0;
-        o[(r++) * ld] = vx[i];
-        o[(r++) * ld] = vy[i];
-        o[(r++) * ld] = px[i];
-        o[(r++) * ld] = py[i];
+        st_stream(o + (int64_t)(r++) * ld + lo, vx[i]);
+        st_stream(o + (int64_t)(r++) * ld + lo, vy[i]);
+        st_stream(o + (int64_t)(r++) * ld + lo, px[i]);
+        st_stream(o + (int64_t)(r++) * ld + lo, py[i]);
 #pragma unroll
         for (int l = A; l < E; ++l) {
-          o[(r++) * ld] = px[l] - px[i];
-          o[(r++) * ld] = py[l] - py[i];
+          st_stream(o + (int64_t)(r++) * ld + lo, px[l] - px[i]);
+          st_stream(o + (int64_t)(r++) * ld + lo, py[l] - py[i]);
         }
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          o[(r++) * ld] = px[j] - px[i];
-          o[(r++) * ld] = py[j] - py[i];
+          st_stream(o + (int64_t)(r++) * ld + lo, px[j] - px[i]);
+          st_stream(o + (int64_t)(r++) * ld + lo, py[j] - py[i]);
         }
-        if (KIND == MPE_SIMPLE_TAG) {
+        if (TAG) {
 #pragma unroll
           for (int j = NADV; j < A; ++j) {
             if (j == i) continue;
-            o[(r++) * ld] = vx[j];
-            o[(r++) * ld] = vy[j];
+            st_stream(o + (int64_t)(r++) * ld + lo, vx[j]);
+            st_stream(o + (int64_t)(r++) * ld + lo, vy[j]);
           }
         } else {
-          for (int z = 0; z < d.dim_c * (A - 1); ++z) o[(r++) * ld] = T(0);
+          for (int z = 0; z < d.dim_c * (A - 1); ++z) st_stream(o + (int64_t)(r++) * ld + lo, T(0));
         }
       }
     }
@@ -113,7 +141,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
       T rew[A];
       int coll[A];
       int extra = 0;
-      if (KIND == MPE_SIMPLE_TAG) {
+      if (TAG) {
         int total = 0;
 #pragma unroll
         for (int a = 0; a < NADV; ++a) coll[a] = 0;
@@ -128,17 +156,17 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
           }
           total += n;
           coll[g] = 0;
-          T r = bit(d.collide, g) ? -T(10) * T(n) : T(0);  // simple_tag.py:97-100
-          r = r - tag_bound<T>(t_abs<T>(px[g]));          // simple_tag.py:109-111
-          r = r - tag_bound<T>(t_abs<T>(py[g]));
+          T r = -T(10) * T(n);                                 // simple_tag.py:97-100
+          r = r - tag_bound_sel<T>(t_abs<T>(px[g]));          // simple_tag.py:109-111
+          r = r - tag_bound_sel<T>(t_abs<T>(py[g]));
           rew[g] = r;
         }
 #pragma unroll
-        for (int a = 0; a < NADV; ++a) rew[a] = bit(d.collide, a) ? T(10) * T(total) : T(0);
+        for (int a = 0; a < NADV; ++a) rew[a] = T(10) * T(total);  // simple_tag.py:124-128
         extra = total;
         if (want_info && active) {
 #pragma unroll
-          for (int i = 0; i < A; ++i) p.info[(int64_t)i * ld + env] = T(coll[i]);
+          for (int i = 0; i < A; ++i) st_stream(p.info + blk0 + (int64_t)i * ld + lo, T(coll[i]));
         }
       } else {
         T r0 = T(0), md = T(0);
@@ -160,51 +188,68 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
         for (int i = 0; i < A; ++i) {
           T r = r0;
           int c = 0;
-          if (bit(d.collide, i)) {
 #pragma unroll
-            for (int a = 0; a < A; ++a) {  // includes a == i (simple_spread.py:78-80)
-              if (touching<T>(px[a] - px[i], py[a] - py[i], d.size[a] + d.size[i])) {
-                r = r - T(1);
-                c += 1;
-              }
-            }
+          for (int a = 0; a < A; ++a) {  // includes a == i (simple_spread.py:78-80)
+            const bool hit = touching<T>(px[a] - px[i], py[a] - py[i], d.size[a] + d.size[i]);
+            r = hit ? r - T(1) : r;
+            c += hit ? 1 : 0;
           }
           rew[i] = r;
           coll[i] = c;
           if (want_info && active) {
-            T *ir = p.info + (int64_t)(4 * i) * ld + env;
-            ir[0] = r; ir[ld] = T(c); ir[2 * ld] = md; ir[3 * ld] = T(occ);
+            T *ir = p.info + blk0 + (int64_t)(4 * i) * ld + lo;
+            st_stream(ir, r); st_stream(ir + ld, T(c)); st_stream(ir + 2 * ld, md); st_stream(ir + 3 * ld, T(occ));
           }
         }
         extra = occ;
       }
       if (want_rew && active) {
 #pragma unroll
-        for (int i = 0; i < A; ++i) p.rew[(int64_t)i * ld + env] = rew[i];
+        for (int i = 0; i < A; ++i) st_stream(p.rew + blk0 + (int64_t)i * ld + lo, rew[i]);
       }
-      // ---- per-workgroup statistics: wavefront reduction, then one row update per block ------------
+      // ---- per-workgroup statistics: wavefront reductions, then one row update per block ---------
+      // Small integer counters (<= 3 per lane, so <= 192 per wavefront) are packed four to a word
+      // and summed with one integer butterfly; only the float rewards need a double butterfly.
       if (want_stats) {
         constexpr int W = 2 * A + 2;
-        __shared__ double sred[kSmallThreads / 64][W];
+        constexpr int NW = kSmallThreads / 64;
+        static_assert(A <= 4 && (!TAG || (A - NADV == 1 && NADV <= 3)), "counter packing assumes the stock worlds");
+        __shared__ double sred[NW][W];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double v[W];
+        uint32_t packed = 0;
 #pragma unroll
-        for (int i = 0; i < A; ++i) {
-          v[i] = active ? (double)rew[i] : 0.0;
-          v[A + i] = active ? (double)coll[i] : 0.0;
+        for (int i = 0; i < (TAG ? NADV : A); ++i) packed |= (uint32_t)coll[i] << (8 * i);
+        if (!TAG) packed |= (uint32_t)extra << 24;
+        packed = wave_sum_u32(active ? packed : 0u);
+        const double n_active = (double)__builtin_popcountll(__ballot(active));
+        double rsum[A];
+        if (TAG) {
+          rsum[NADV] = group_sum(active ? (double)rew[NADV] : 0.0, 64);
+        } else {
+#pragma unroll
+          for (int i = 0; i < A; ++i) rsum[i] = group_sum(active ? (double)rew[i] : 0.0, 64);
         }
-        v[2 * A] = active ? (double)extra : 0.0;
-        v[2 * A + 1] = active ? 1.0 : 0.0;
+        if (lane == 0) {
+          double csum[A], tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-          const double s = group_sum(v[k], 64);
-          if (lane == 0) sred[wave][k] = s;
+          for (int i = 0; i < A; ++i) {
+            csum[i] = (TAG && i >= NADV) ? 0.0 : (double)((packed >> (8 * i)) & 0xFFu);
+            tot += csum[i];
+          }
+#pragma unroll
+          for (int i = 0; i < A; ++i) {
+            // simple_tag adversaries all get 10 * total (exact in double)
+            sred[wave][i] = (TAG && i < NADV) ? 10.0 * tot : rsum[i];
+            sred[wave][A + i] = csum[i];
+          }
+          sred[wave][2 * A] = TAG ? tot : (double)(packed >> 24);
+          sred[wave][2 * A + 1] = n_active;
         }
         __syncthreads();
         if (threadIdx.x < W) {
           double s = 0.0;
 #pragma unroll
-          for (int w = 0; w < kSmallThreads / 64; ++w) s += sred[w][threadIdx.x];
+          for (int w = 0; w < NW; ++w) s += sred[w][threadIdx.x];
           p.stats[(int64_t)blockIdx.x * W + threadIdx.x] += s;
         }
       }

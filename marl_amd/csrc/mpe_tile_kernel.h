@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
               if (!bit(d.collide, b)) continue;
               T fx, fy;
               pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
-                            sa + d.size[b], d.k, d.cforce, fx, fy);
+                            sa + d.size[b], d, fx, fy);
               Fx = fx + Fx;
               Fy = fy + Fy;
             }
@@ -115,31 +115,31 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
-          o[0] = sVel[(2 * i) * TILE + lane];
-          o[ld] = sVel[(2 * i + 1) * TILE + lane];
-          o[2 * ld] = pix;
-          o[3 * ld] = piy;
+          st_stream(o, sVel[(2 * i) * TILE + lane]);
+          st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+          st_stream(o + 2 * ld, pix);
+          st_stream(o + 3 * ld, piy);
           o += 4 * ld;
           for (int l = A; l < E; ++l) {
-            o[0] = sPos[(2 * l) * TILE + lane] - pix;
-            o[ld] = sPos[(2 * l + 1) * TILE + lane] - piy;
+            st_stream(o, sPos[(2 * l) * TILE + lane] - pix);
+            st_stream(o + ld, sPos[(2 * l + 1) * TILE + lane] - piy);
             o += 2 * ld;
           }
           for (int j = 0; j < A; ++j) {
             if (j == i) continue;
-            o[0] = sPos[(2 * j) * TILE + lane] - pix;
-            o[ld] = sPos[(2 * j + 1) * TILE + lane] - piy;
+            st_stream(o, sPos[(2 * j) * TILE + lane] - pix);
+            st_stream(o + ld, sPos[(2 * j + 1) * TILE + lane] - piy);
             o += 2 * ld;
           }
           if (d.kind == MPE_SIMPLE_TAG) {
             for (int j = 0; j < A; ++j) {
               if (j == i || bit(d.adversary, j)) continue;
-              o[0] = sVel[(2 * j) * TILE + lane];
-              o[ld] = sVel[(2 * j + 1) * TILE + lane];
+              st_stream(o, sVel[(2 * j) * TILE + lane]);
+              st_stream(o + ld, sVel[(2 * j + 1) * TILE + lane]);
               o += 2 * ld;
             }
           } else {
-            for (int z = 0; z < d.dim_c * (A - 1); ++z) { o[0] = T(0); o += ld; }
+            for (int z = 0; z < d.dim_c * (A - 1); ++z) { st_stream(o, T(0)); o += ld; }
           }
         }
       }
@@ -166,9 +166,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
               if (bit(d.collide, i)) r_i = -T(10) * T(n);
               r_i = r_i - tag_bound<T>(t_abs<T>(pix));
               r_i = r_i - tag_bound<T>(t_abs<T>(piy));
-              if (want_rew && active) p.rew[(int64_t)i * ld + env] = r_i;
+              if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
             }
-            if (want_info && active) p.info[(int64_t)i * ld + env] = i_adv ? T(n) : T(0);
+            if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, i_adv ? T(n) : T(0));
             if (want_stats) {
               const double s_c = group_sum(active && i_adv ? (double)n : 0.0, TILE);
               if (lane == 0) srow[A + i] += s_c;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
           for (int i = chunk; i < A; i += NCH) {
             if (!bit(d.adversary, i)) continue;
             const T r_i = bit(d.collide, i) ? T(10) * T(total) : T(0);
-            if (want_rew && active) p.rew[(int64_t)i * ld + env] = r_i;
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
             if (want_stats) {
               const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
               if (lane == 0) srow[i] += s_r;
@@ -235,10 +235,10 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
               }
             }
             if (active) {
-              if (want_rew) p.rew[(int64_t)i * ld + env] = r_i;
+              if (want_rew) st_stream(p.rew + (int64_t)i * ld + env, r_i);
               if (want_info) {
                 T *ir = p.info + (int64_t)(4 * i) * ld + env;
-                ir[0] = r_i; ir[ld] = T(c_i); ir[2 * ld] = md; ir[3 * ld] = T(occ);
+                st_stream(ir, r_i); st_stream(ir + ld, T(c_i)); st_stream(ir + 2 * ld, md); st_stream(ir + 3 * ld, T(occ));
               }
             }
             if (want_stats) {

@@ -1,0 +1,102 @@
+// Access-pattern probe for the small-world env-step kernel: NR read rows + NW write rows of an
+// SoA [row][B] layout, one (or V) env(s) per lane, trivial arithmetic.  Tells what HBM rate the
+// access pattern itself can reach on MI355X, independent of the physics.
+//   hipcc -O3 --offload-arch=gfx950 tools/stream_probe.hip -o gpurun_out/stream_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int V> struct Vec;
+template <> struct Vec<1> { using type = float; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <> struct Vec<2> { using type = f32x2; };
+template <> struct Vec<4> { using type = f32x4; };
+
+template <int NR, int NW, int V, bool NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void soa_kernel(const float *__restrict__ in, float *__restrict__ out, long B) {
+  using VT = typename Vec<V>::type;
+  const long i = ((long)blockIdx.x * THREADS + threadIdx.x) * V;
+  if (i >= B) return;
+  float acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = 0.f;
+  float r[NR][V];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    VT x = *reinterpret_cast<const VT *>(in + (long)k * B + i);
+#pragma unroll
+    for (int v = 0; v < V; ++v) r[k][v] = reinterpret_cast<float *>(&x)[v];
+  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] += r[k][v];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    VT y;
+#pragma unroll
+    for (int v = 0; v < V; ++v) reinterpret_cast<float *>(&y)[v] = acc[v] + r[k % NR][v] * (float)k;
+    VT *p = reinterpret_cast<VT *>(out + (long)k * B + i);
+    if (NT) __builtin_nontemporal_store(y, p); else *p = y;
+  }
+}
+
+__global__ void copy4(const float4 *__restrict__ in, float4 *__restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i];
+}
+
+template <typename F>
+static float time_it(F f, int iters = 20) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) f();
+  hipEventRecord(a);
+  for (int i = 0; i < iters; ++i) f();
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / iters;
+}
+
+template <int NR, int NW, int V, bool NT, int THREADS>
+static void run(const char *name, const float *in, float *out, long B) {
+  const long nthreads = B / V;
+  dim3 grid((unsigned)((nthreads + THREADS - 1) / THREADS));
+  float ms = time_it([&] { hipLaunchKernelGGL((soa_kernel<NR, NW, V, NT, THREADS>), grid, dim3(THREADS), 0, 0, in, out, B); });
+  double bytes = (double)(NR + NW) * B * 4;
+  printf("%-34s NR=%3d NW=%3d V=%d NT=%d T=%4d : %8.1f us  %7.1f GB/s\n", name, NR, NW, V, (int)NT, THREADS, ms * 1e3, bytes / ms / 1e6);
+}
+
+int main() {
+  const long B = 1 << 20;
+  float *in, *out;
+  CK(hipMalloc(&in, (size_t)64 * B * 4));
+  CK(hipMalloc(&out, (size_t)128 * B * 4));
+  CK(hipMemset(in, 0, (size_t)64 * B * 4));
+  CK(hipMemset(out, 0, (size_t)128 * B * 4));
+  {
+    const long n = (long)40 * B / 4;  // 160 MB read + 160 MB write
+    float ms = time_it([&] { hipLaunchKernelGGL(copy4, dim3(256 * 8), dim3(256), 0, 0, (const float4 *)in, (float4 *)out, n); });
+    printf("%-34s : %8.1f us  %7.1f GB/s\n", "copy float4 160MB+160MB", ms * 1e3, 2.0 * n * 16 / ms / 1e6);
+  }
+  run<40, 86, 1, false, 256>("soa tag-shaped", in, out, B);
+  run<40, 86, 1, true, 256>("soa tag-shaped nt", in, out, B);
+  run<40, 86, 2, false, 256>("soa tag-shaped x2", in, out, B);
+  run<40, 86, 2, true, 256>("soa tag-shaped x2 nt", in, out, B);
+  run<40, 86, 4, false, 256>("soa tag-shaped x4", in, out, B);
+  run<40, 86, 4, true, 256>("soa tag-shaped x4 nt", in, out, B);
+  run<40, 86, 1, false, 64>("soa tag-shaped T64", in, out, B);
+  run<40, 86, 1, false, 128>("soa tag-shaped T128", in, out, B);
+  run<40, 86, 1, false, 512>("soa tag-shaped T512", in, out, B);
+  run<40, 86, 1, false, 1024>("soa tag-shaped T1024", in, out, B);
+  run<40, 40, 1, false, 256>("soa 40r/40w", in, out, B);
+  run<40, 40, 4, false, 256>("soa 40r/40w x4", in, out, B);
+  run<8, 8, 1, false, 256>("soa 8r/8w", in, out, B);
+  run<8, 8, 4, false, 256>("soa 8r/8w x4", in, out, B);
+  run<2, 2, 4, false, 256>("soa 2r/2w x4", in, out, B);
+  return 0;
+}
