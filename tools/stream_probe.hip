@@ -49,6 +49,29 @@ __global__ void copy4(const float4 *__restrict__ in, float4 *__restrict__ out, l
   for (; i < n; i += stride) out[i] = in[i];
 }
 
+template <bool NT>
+__global__ void copy4v(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    f32x4 v = NT ? __builtin_nontemporal_load(in + i) : in[i];
+    if (NT) __builtin_nontemporal_store(v, out + i); else out[i] = v;
+  }
+}
+__global__ void fill4(f32x4 *__restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  f32x4 v = {1.f, 2.f, 3.f, 4.f};
+  for (; i < n; i += stride) __builtin_nontemporal_store(v, out + i);
+}
+__global__ void read4(const f32x4 *__restrict__ in, float *__restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i < n; i += stride) acc += __builtin_nontemporal_load(in + i);
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
+}
+
 template <typename F>
 static float time_it(F f, int iters = 20) {
   hipEvent_t a, b;
@@ -82,6 +105,23 @@ int main() {
     const long n = (long)40 * B / 4;  // 160 MB read + 160 MB write
     float ms = time_it([&] { hipLaunchKernelGGL(copy4, dim3(256 * 8), dim3(256), 0, 0, (const float4 *)in, (float4 *)out, n); });
     printf("%-34s : %8.1f us  %7.1f GB/s\n", "copy float4 160MB+160MB", ms * 1e3, 2.0 * n * 16 / ms / 1e6);
+  }
+  {
+    const long n = (long)256 * 1024 * 1024 / 16;  // 256 MiB each way (beyond the Infinity Cache together)
+    float *big_in, *big_out;
+    CK(hipMalloc(&big_in, n * 16)); CK(hipMalloc(&big_out, n * 16));
+    CK(hipMemset(big_in, 0, n * 16));
+    for (int g : {1024, 2048, 4096, 8192, 16384, 65536}) {
+      float ms = time_it([&] { hipLaunchKernelGGL(copy4v<false>, dim3(g), dim3(256), 0, 0, (const f32x4 *)big_in, (f32x4 *)big_out, n); });
+      float ms2 = time_it([&] { hipLaunchKernelGGL(copy4v<true>, dim3(g), dim3(256), 0, 0, (const f32x4 *)big_in, (f32x4 *)big_out, n); });
+      printf("copy 256MiB+256MiB grid=%6d : %7.1f GB/s   nt: %7.1f GB/s\n", g, 2.0 * n * 16 / ms / 1e6, 2.0 * n * 16 / ms2 / 1e6);
+    }
+    for (int g : {2048, 8192, 65536}) {
+      float ms = time_it([&] { hipLaunchKernelGGL(fill4, dim3(g), dim3(256), 0, 0, (f32x4 *)big_out, n); });
+      float ms2 = time_it([&] { hipLaunchKernelGGL(read4, dim3(g), dim3(256), 0, 0, (const f32x4 *)big_in, out, n); });
+      printf("write-only 256MiB grid=%6d : %7.1f GB/s   read-only: %7.1f GB/s\n", g, 1.0 * n * 16 / ms / 1e6, 1.0 * n * 16 / ms2 / 1e6);
+    }
+    hipFree(big_in); hipFree(big_out);
   }
   run<40, 86, 1, false, 256>("soa tag-shaped", in, out, B);
   run<40, 86, 1, true, 256>("soa tag-shaped nt", in, out, B);
