@@ -49,6 +49,17 @@ def algorithmic_elems(env, with_info=True):
     return 5 * A + 2 * E + 2 * A + 4 * A + obs + A + A * info_w
 
 
+def measured_traffic(workload):
+    """HBM bytes per fused launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    tools/summarize_pmc.py); None when no pass was recorded for this workload."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % workload)
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))['kernels']
+    fused = [v for k, v in ks.items() if 'true, true>' in k]
+    return fused[0]['traffic_bytes'] if fused else None
+
+
 def cpu_baseline(seconds=12.0):
     """Reference's serial numpy loop, restated (oracle.SerialEnv: one Python object per entity,
     validated bit-exact against the reference), on ONE host core: simple_tag, 25-step episodes
@@ -136,6 +147,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # prime every code path once (module load, first-launch costs, allocator) before the W warmup
+    # steps, so that the timed region is steady state whatever W is
+    env.reset()
+    env.step(pool[0])
+    stats.read()
+    stats.reset()
+    torch.cuda.synchronize()
+
     run(args.warmup)
     events = None if args.no_events else []
     fence()
@@ -175,7 +194,8 @@ def main():
                        'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
                        'parallelism': 'env-sharded dp%d' % world_size},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': measured_traffic(args.workload) if B == envs_per_gpu else None,
                          'kernel': 'mpe env_step (fused)', 'algorithmic_bytes_per_launch': bytes_per_launch,
                          'bytes_per_env_step': elems * env.world.pos.element_size(),
                          'avg_launch_ms': kern_ms, 'median_launch_ms': kern_med,

@@ -18,7 +18,9 @@ MPE_SIMPLE_TAG = 0
 MPE_SIMPLE_SPREAD = 1
 ABI_VERSION = 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libmpe_hip.so')
+# MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
+_LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                           'libmpe_hip.so')
 
 
 class ScenarioDesc(C.Structure):

@@ -17,6 +17,8 @@ namespace mpe {
 template <typename T>
 struct DevDesc {
   int32_t kind, A, L, E, dim_c, obs_total, info_w, n_adv;
+  int32_t n_good;       // agents that are not adversaries
+  int32_t ncol_prefix;  // >= 0: exactly the entities [0, ncol_prefix) collide (fast pair loop); -1: irregular
   T dt, damp1 /* 1 - damping */, cforce, k, inv_k /* f32 fast path only */;
   T size[MPE_MAX_ENTITIES];
   T mass[MPE_MAX_AGENTS];
@@ -27,6 +29,8 @@ struct DevDesc {
   uint32_t movable[MPE_MAX_ENTITIES / 32];
   uint32_t collide[MPE_MAX_ENTITIES / 32];
   uint32_t adversary[MPE_MAX_AGENTS / 32];
+  uint8_t adv_list[MPE_MAX_AGENTS];   // agent indices of the adversaries, ascending
+  uint8_t good_list[MPE_MAX_AGENTS];  // agent indices of the good agents, ascending
 };
 
 template <typename T>

@@ -123,12 +123,19 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     d.u_noise[a] = (T)h->u_noise[a];
     if (h->kind == MPE_SIMPLE_TAG && h->adversary[a]) {
       d.adversary[a >> 5] |= 1u << (a & 31);
-      d.n_adv++;
+      d.adv_list[d.n_adv++] = (uint8_t)a;
+    } else {
+      d.good_list[d.n_good++] = (uint8_t)a;
     }
     d.obs_row0[a] = row;
     row += obs_dim_of(h, a);
   }
   d.obs_total = row;
+  int ncol = 0;
+  while (ncol < d.E && h->collide[ncol]) ++ncol;
+  d.ncol_prefix = ncol;
+  for (int e = ncol; e < d.E; ++e)
+    if (h->collide[e]) d.ncol_prefix = -1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +161,21 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
 static bool g_force_tile = false;  // test hook: route the stock worlds through the tile kernel too
 extern "C" void mpe_debug_force_tile_kernel(int on) { g_force_tile = on != 0; }
 
+template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
+static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
+  constexpr int TILE = tile_envs<T>();
+  const size_t lds = tile_lds_bytes<T>(h, THREADS);
+  auto kern = tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS>;
+  if (lds > 64 * 1024) {
+    if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid((unsigned)tile_grid(p.B, TILE)), block(THREADS);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, bool DO_STEP, bool DO_OBS>
 static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   const SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
@@ -175,17 +197,11 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s
     }
     return (int)hipGetLastError();
   }
-  constexpr int TILE = tile_envs<T>();
-  const size_t lds = tile_lds_bytes<T>(h);
-  auto kern = tile_kernel<T, TILE, DO_STEP, DO_OBS>;
-  if (lds > 64 * 1024) {
-    if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  const dim3 grid((unsigned)tile_grid(p.B, TILE)), block(kTileThreads);
-  hipLaunchKernelGGL(kern, grid, block, lds, s, p);
-  return (int)hipGetLastError();
+  // Large worlds are LDS-limited to 1-2 workgroups per CU: give those workgroups more wavefronts so
+  // the compute-heavy pair phase and the store-heavy observation phase still find work to overlap.
+  const int E = h->n_agents + h->n_landmarks;
+  if (E > 32) return launch_tile<T, 512, DO_STEP, DO_OBS>(h, p, s);
+  return launch_tile<T, 256, DO_STEP, DO_OBS>(h, p, s);
 }
 
 extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dtype_bytes) {

@@ -23,11 +23,9 @@
 
 namespace mpe {
 
-constexpr int kTileThreads = 256;
-
-template <typename T, int TILE, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) {
-  constexpr int NCH = kTileThreads / TILE;
+template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
+  constexpr int NCH = THREADS / TILE;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevDesc<T> &d = p.d;
   const int A = d.A, L = d.L, E = d.E;
@@ -70,13 +68,39 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
           if (bit(d.collide, a)) {
             const T pax = sPos[(2 * a) * TILE + lane], pay = sPos[(2 * a + 1) * TILE + lane];
             const T sa = d.size[a];
-            for (int b = a + 1; b < E; ++b) {
-              if (!bit(d.collide, b)) continue;
-              T fx, fy;
-              pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
-                            sa + d.size[b], d, fx, fy);
-              Fx = fx + Fx;
-              Fy = fy + Fy;
+            int b = a + 1;
+            if (d.ncol_prefix >= 0) {
+              // regular worlds (all of [0, ncol) collide): 4 independent pair evaluations per trip
+              // for instruction-level parallelism; the additions stay in ascending-b order.
+              const int bend = d.ncol_prefix;
+              for (; b + 3 < bend; b += 4) {
+                T fx[4], fy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  pair_force<T>(pax - sPos[(2 * (b + u)) * TILE + lane], pay - sPos[(2 * (b + u) + 1) * TILE + lane],
+                                sa + d.size[b + u], d, fx[u], fy[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  Fx = fx[u] + Fx;
+                  Fy = fy[u] + Fy;
+                }
+              }
+              for (; b < bend; ++b) {
+                T fx, fy;
+                pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
+                              sa + d.size[b], d, fx, fy);
+                Fx = fx + Fx;
+                Fy = fy + Fy;
+              }
+            } else {
+              for (; b < E; ++b) {
+                if (!bit(d.collide, b)) continue;
+                T fx, fy;
+                pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
+                              sa + d.size[b], d, fx, fy);
+                Fx = fx + Fx;
+                Fy = fy + Fy;
+              }
             }
           }
           integrate_vel<T>(vx, vy, Fx, Fy, d.mass[a], d.damp1, d.dt, d.max_speed[a]);
@@ -147,51 +171,55 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
       // ---- phase 3b: reward / info (sAux aliases sVel from here on) ---------------------------------------------------------------
       if (want_rew || want_info || want_stats) {
         if (d.kind == MPE_SIMPLE_TAG) {
-          // hit(g,a) = is_collision(good g, adversary a) (simple_tag.py:69-73)
+          // hit(g,a) = is_collision(good g, adversary a) (simple_tag.py:69-73), each pair evaluated
+          // once by the chunk that owns g; per-adversary counts meet in LDS (ds_add, rare).
+          int *sCnt = reinterpret_cast<int *>(sAux);        // [n_adv][TILE]
+          int *sTot = sCnt + d.n_adv * TILE;                // [NCH][TILE]
+          for (int ai = chunk; ai < d.n_adv; ai += NCH) sCnt[ai * TILE + lane] = 0;
+          __syncthreads();
           int part = 0;  // this chunk's share of sum_{g,a} hit
-          for (int i = chunk; i < A; i += NCH) {
-            const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
-            const bool i_adv = bit(d.adversary, i);
+          for (int gi = chunk; gi < d.n_good; gi += NCH) {
+            const int g = d.good_list[gi];
+            const T pgx = sPos[(2 * g) * TILE + lane], pgy = sPos[(2 * g + 1) * TILE + lane];
+            const T sg = d.size[g];
             int n = 0;
-            for (int j = 0; j < A; ++j) {
-              if (bit(d.adversary, j) == i_adv) continue;
-              n += touching<T>(pix - sPos[(2 * j) * TILE + lane], piy - sPos[(2 * j + 1) * TILE + lane],
-                               d.size[i] + d.size[j])
-                       ? 1 : 0;
-            }
-            T r_i = T(0);
-            if (i_adv) {
-              part += n;  // benchmark_data (simple_tag.py:57-64); reward filled in after the reduce
-            } else {      // agent_reward (simple_tag.py:89-113)
-              if (bit(d.collide, i)) r_i = -T(10) * T(n);
-              r_i = r_i - tag_bound<T>(t_abs<T>(pix));
-              r_i = r_i - tag_bound<T>(t_abs<T>(piy));
-              if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
-            }
-            if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, i_adv ? T(n) : T(0));
-            if (want_stats) {
-              const double s_c = group_sum(active && i_adv ? (double)n : 0.0, TILE);
-              if (lane == 0) srow[A + i] += s_c;
-              if (!i_adv) {
-                const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
-                if (lane == 0) srow[i] += s_r;
+            for (int ai = 0; ai < d.n_adv; ++ai) {
+              const int a = d.adv_list[ai];
+              if (touching<T>(pgx - sPos[(2 * a) * TILE + lane], pgy - sPos[(2 * a + 1) * TILE + lane],
+                              sg + d.size[a])) {
+                ++n;
+                atomicAdd(&sCnt[ai * TILE + lane], 1);
               }
             }
+            part += n;
+            // agent_reward (simple_tag.py:89-113)
+            T r_g = bit(d.collide, g) ? -T(10) * T(n) : T(0);
+            r_g = r_g - tag_bound<T>(t_abs<T>(pgx));
+            r_g = r_g - tag_bound<T>(t_abs<T>(pgy));
+            if (want_rew && active) st_stream(p.rew + (int64_t)g * ld + env, r_g);
+            if (want_info && active) st_stream(p.info + (int64_t)g * ld + env, T(0));  // simple_tag.py:65-66
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_g : 0.0, TILE);
+              if (lane == 0) srow[g] += s_r;
+            }
           }
-          int *sCnt = reinterpret_cast<int *>(sAux);
-          sCnt[chunk * TILE + lane] = part;
+          sTot[chunk * TILE + lane] = part;
           __syncthreads();
           int total = 0;
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) total += sCnt[c * TILE + lane];
-          // adversary_reward (simple_tag.py:115-129): same value for every adversary
-          for (int i = chunk; i < A; i += NCH) {
-            if (!bit(d.adversary, i)) continue;
+          for (int c = 0; c < NCH; ++c) total += sTot[c * TILE + lane];
+          // adversary_reward (simple_tag.py:115-129): same value for every adversary;
+          // benchmark_data (simple_tag.py:57-64): goods touching this adversary
+          for (int ai = chunk; ai < d.n_adv; ai += NCH) {
+            const int i = d.adv_list[ai];
+            const int n = sCnt[ai * TILE + lane];
             const T r_i = bit(d.collide, i) ? T(10) * T(total) : T(0);
             if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, T(n));
             if (want_stats) {
               const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
-              if (lane == 0) srow[i] += s_r;
+              const double s_c = group_sum(active ? (double)n : 0.0, TILE);
+              if (lane == 0) { srow[i] += s_r; srow[A + i] += s_c; }
             }
           }
           if (want_stats && chunk == 0) {
@@ -262,13 +290,13 @@ __global__ __launch_bounds__(kTileThreads) void tile_kernel(const KParams<T> p) 
 template <typename T>
 constexpr int tile_envs() { return sizeof(T) == 4 ? 64 : 32; }
 
-// LDS bytes: pos rows + max(vel rows, aux rows); aux = NCH int rows (tag) or L rows of T (spread).
+// LDS bytes: pos rows + max(vel rows, aux rows); aux = (n_adv + NCH) int rows (tag) or L rows of T (spread).
 template <typename T>
-inline size_t tile_lds_bytes(const mpe_scenario_desc *h) {
+inline size_t tile_lds_bytes(const mpe_scenario_desc *h, int threads) {
   constexpr int TILE = tile_envs<T>();
-  constexpr int NCH = kTileThreads / TILE;
+  const int NCH = threads / TILE;
   const int E = h->n_agents + h->n_landmarks;
-  size_t aux = h->kind == MPE_SIMPLE_TAG ? (size_t)NCH * TILE * sizeof(int)
+  size_t aux = h->kind == MPE_SIMPLE_TAG ? (size_t)(NCH + h->n_agents) * TILE * sizeof(int)
                                          : (size_t)h->n_landmarks * TILE * sizeof(T);
   size_t velb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
   if (velb < aux) velb = aux;

@@ -4,7 +4,7 @@ small JSON under profiles/.  Units and the gfx950 correction follow
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB; FETCH_SIZE reads exactly
 half of the bytes of a coalesced streaming read on gfx950, so it is doubled; WRITE_SIZE is exact.
 
-    python tools/summarize_pmc.py gpurun_out/pmc profiles/r1_pmc_simple_tag_1M_f32.json <kernel substring>
+    python tools/summarize_pmc.py gpurun_out/pmc profiles/pmc_simple_tag_1M_f32.json <kernel substring>
 """
 import collections
 import csv
