@@ -93,6 +93,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='simple_tag_1M_f32', choices=sorted(WORKLOADS))
     ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
+    ap.add_argument('--action-buffers', type=int, default=4,
+                    help='resident action tensors rotated step by step (1 = the same tensor every step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (roofline from wall time)')
     args = ap.parse_args()
@@ -121,7 +123,7 @@ def main():
     n = env.n
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     pool = [torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1).contiguous()
-            for _ in range(4)]
+            for _ in range(args.action_buffers)]
     stats = EpisodeStats(env.world)
     stats_total = torch.zeros(2 * n + 2, dtype=torch.float64, device=device)
 
@@ -136,11 +138,11 @@ def main():
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                env.step(pool[tt & 3])
+                env.step(pool[tt % len(pool)])
                 e1.record()
                 events.append((e0, e1))
             else:
-                env.step(pool[tt & 3])
+                env.step(pool[tt % len(pool)])
 
     def fence():
         if world_size > 1:
@@ -151,7 +153,8 @@ def main():
     # steps, so that the timed region is steady state whatever W is
     env.reset()
     env.step(pool[0])
-    stats.read()
+    stats_total.add_(stats.read())      # also loads torch's f64 add kernel (a ~20 ms one-time cost)
+    stats_total.zero_()
     stats.reset()
     torch.cuda.synchronize()
 
@@ -189,7 +192,7 @@ def main():
             'dtype': 'f32' if dtype == torch.float32 else 'f64', 'data': 'synthetic',
             'config': {'workload': args.workload, 'scenario': scenario, 'envs_per_gpu': B,
                        'agents': n, 'entities': len(env.world.entities), 'episode_len': EPISODE_LEN,
-                       'actions': 'softmax(N(0,1)) soft one-hot, 4 resident buffers rotated',
+                       'actions': 'softmax(N(0,1)) soft one-hot, %d resident buffers rotated' % len(pool),
                        'reset_in_timed_region': True, 'benchmark_info': True,
                        'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
                        'parallelism': 'env-sharded dp%d' % world_size},

@@ -148,7 +148,8 @@ class World(object):
         self.obs_views = None
         self.stats = None          # per-workgroup statistics rows (enable_stats())
         self._tick = 0             # bumped whenever the state changes
-        self._gather_tick = -1     # tick the gather buffers correspond to
+        self._gather_tick = -1     # tick the gather buffers (obs, rew, info) correspond to
+        self._obs_tick = -1        # tick the obs buffer alone corresponds to
         # device reset RNG: Philox key / per-reset counter / global id of env 0 (multi-GPU shards)
         self.seed = 0
         self.episode = 0
@@ -212,6 +213,18 @@ class World(object):
         for i in range(A):
             r0, n = _hip.lib.mpe_obs_row0(d, i), _hip.lib.mpe_obs_dim(d, i)
             self.obs_views.append(self.obs[r0:r0 + n].t())      # [B, obs_dim_i], strides (1, B)
+
+    def gather_obs(self):
+        """Observations only (what MultiAgentEnv.reset() returns, environment.py:124-129)."""
+        if self.obs is None:
+            self._alloc_outputs()
+        if self._gather_tick == self._tick or self._obs_tick == self._tick:
+            return
+        d = self.descriptor()
+        fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
+        _hip.check(fn(d, self.num_envs, self.num_envs, self.pos.data_ptr(), self.vel.data_ptr(),
+                      self.obs.data_ptr(), None, None, _hip.stream_of(self.device)), 'mpe_observe')
+        self._obs_tick = self._tick
 
     def gather(self, force=False):
         """Observation / reward / benchmark_data of every agent for the current state: one launch

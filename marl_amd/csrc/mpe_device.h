@@ -47,10 +47,40 @@ struct KParams {
 // MI355X with the simple_tag access shape (40 read rows + 86 write rows, 1M envs): 4.8 -> 7.4 TB/s
 // (tools/stream_probe.hip).
 template <typename T>
-__device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(T *p, T v) {
+#ifdef MPE_NO_NT_STORE
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
 // Read-once inputs (actions, noise).
 template <typename T>
-__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ T ld_stream(const T *p) {
+#ifdef MPE_NO_NT_LOAD
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+
+// Env state (pos / vel): re-read by the next step, default cache policy.
+template <typename T>
+__device__ __forceinline__ T ld_state(const T *p) {
+#ifdef MPE_NT_STATE_LOAD
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void st_state(T *p, T v) {
+#ifdef MPE_NT_STATE_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 __device__ __forceinline__ bool bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 

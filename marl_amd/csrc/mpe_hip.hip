@@ -176,26 +176,33 @@ static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStrea
   return (int)hipGetLastError();
 }
 
+template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool DO_STEP, bool DO_OBS>
+static int launch_small(const KParams<T> &p, bool noise, hipStream_t s) {
+  const dim3 grid((unsigned)((p.B + THREADS - 1) / THREADS)), block(THREADS);
+  if (noise)
+    hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, bool DO_STEP, bool DO_OBS>
 static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   const SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
   if (sv != SMALL_NONE) {
-    const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
     bool noise = false;
     if (DO_STEP && p.noise != nullptr)
       for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
-    if (sv == SMALL_TAG_3_1_2) {
-      if (noise)
-        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-      else
-        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-    } else {
-      if (noise)
-        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_SPREAD, 3, 3, 0, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-      else
-        hipLaunchKernelGGL((small_kernel<T, MPE_SIMPLE_SPREAD, 3, 3, 0, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+    if constexpr (sizeof(T) == 4) {
+      if (small_threads(p.B, 4) == kSmallThreadsBig) {
+        if (sv == SMALL_TAG_3_1_2)
+          return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, kSmallThreadsBig, DO_STEP, DO_OBS>(p, noise, s);
+        return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, kSmallThreadsBig, DO_STEP, DO_OBS>(p, noise, s);
+      }
     }
-    return (int)hipGetLastError();
+    if (sv == SMALL_TAG_3_1_2)
+      return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, kSmallThreads, DO_STEP, DO_OBS>(p, noise, s);
+    return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, kSmallThreads, DO_STEP, DO_OBS>(p, noise, s);
   }
   // Large worlds are LDS-limited to 1-2 workgroups per CU: give those workgroups more wavefronts so
   // the compute-heavy pair phase and the store-heavy observation phase still find work to overlap.
@@ -209,7 +216,7 @@ extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dty
   if (rc) return rc;
   if (B < 1) return MPE_ERR_BATCH;
   if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
-  if (!g_force_tile && small_variant(h) != SMALL_NONE) return (B + kSmallThreads - 1) / kSmallThreads;
+  if (!g_force_tile && small_variant(h) != SMALL_NONE) return (B + small_threads(B, dtype_bytes) - 1) / small_threads(B, dtype_bytes);
   return tile_grid(B, dtype_bytes == 4 ? 64 : 32);
 }
 
@@ -313,27 +320,27 @@ static int reset_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_
   return (int)hipGetLastError();
 }
 
-// One workgroup; thread t owns columns t, t+256, ...; rows summed in a fixed pairwise order:
-// sequential within 64 strided partials per column, then a wavefront tree.
+// One workgroup per column; rows are summed in a fixed order (thread t takes rows t, t+256, ...
+// sequentially, then a wavefront butterfly, then the 4 wavefront partials in a fixed order), so the
+// result is bitwise reproducible for a given (rows, width).
 __global__ __launch_bounds__(256) void stats_reduce_kernel(const double *stats, int64_t rows, int width,
                                                            double *out) {
   __shared__ double sp[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = 0; c < width; ++c) {
-    double s = 0.0;
-    for (int64_t r = threadIdx.x; r < rows; r += 256) s += stats[r * width + c];
-    s = group_sum(s, 64);
-    if (lane == 0) sp[wave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) out[c] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-    __syncthreads();
-  }
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) s += stats[r * width + c];
+  s = group_sum(s, 64);
+  if (lane == 0) sp[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
 }
 
 extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, double *out, void *stream) {
   if (!stats || !out) return MPE_ERR_NULL;
   if (rows < 1 || width < 1) return MPE_ERR_ARG;
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, rows, width, out);
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)width), dim3(256), 0, (hipStream_t)stream, stats, rows,
+                     width, out);
   return (int)hipGetLastError();
 }
 

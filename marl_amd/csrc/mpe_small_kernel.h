@@ -23,16 +23,25 @@
 
 namespace mpe {
 
+// Workgroup size: 1024 lanes when the batch fills the chip (each workgroup then streams one
+// contiguous 4 KiB piece of every SoA row: measured +3.5 % over 256 on MI355X, f32), 256 otherwise so
+// that small batches still spread over all CUs.
+constexpr int kSmallThreadsBig = 1024;
 constexpr int kSmallThreads = 256;
+constexpr int64_t kSmallBigBatch = 1 << 19;
+// f64 needs ~164 VGPRs, which a 1024-lane workgroup cannot have without spilling: f32 only.
+inline int small_threads(int64_t B, int dtype_bytes) {
+  return (dtype_bytes == 4 && B >= kSmallBigBatch) ? kSmallThreadsBig : kSmallThreads;
+}
 
-template <typename T, int KIND, int A, int L, int NADV, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p) {
+template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr bool TAG = KIND == MPE_SIMPLE_TAG;
   constexpr int ECOL = TAG ? E : A;  // entities that collide (stock flags)
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * kSmallThreads;  // wave-uniform
+  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
   const bool active = blk0 + threadIdx.x < p.B;
   // tail lanes shadow the last env (loads stay in bounds) and never store
   const uint32_t lo = active ? threadIdx.x : (uint32_t)(p.B - 1 - blk0);
@@ -41,13 +50,13 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
   T px[E], py[E], vx[A], vy[A];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    px[e] = (gpos + (int64_t)(2 * e) * ld)[lo];
-    py[e] = (gpos + (int64_t)(2 * e + 1) * ld)[lo];
+    px[e] = ld_state(gpos + (int64_t)(2 * e) * ld + lo);
+    py[e] = ld_state(gpos + (int64_t)(2 * e + 1) * ld + lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = (gvel + (int64_t)(2 * a) * ld)[lo];
-    vy[a] = (gvel + (int64_t)(2 * a + 1) * ld)[lo];
+    vx[a] = ld_state(gvel + (int64_t)(2 * a) * ld + lo);
+    vy[a] = ld_state(gvel + (int64_t)(2 * a + 1) * ld + lo);
   }
 
   if (DO_STEP) {
@@ -91,10 +100,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
       px[a] = px[a] + vx[a] * d.dt;
       py[a] = py[a] + vy[a] * d.dt;
       if (active) {
-        (svel + (int64_t)(2 * a) * ld)[lo] = vx[a];
-        (svel + (int64_t)(2 * a + 1) * ld)[lo] = vy[a];
-        (spos + (int64_t)(2 * a) * ld)[lo] = px[a];
-        (spos + (int64_t)(2 * a + 1) * ld)[lo] = py[a];
+        st_state(svel + (int64_t)(2 * a) * ld + lo, vx[a]);
+        st_state(svel + (int64_t)(2 * a + 1) * ld + lo, vy[a]);
+        st_state(spos + (int64_t)(2 * a) * ld + lo, px[a]);
+        st_state(spos + (int64_t)(2 * a + 1) * ld + lo, py[a]);
       }
     }
     if (p.comm != nullptr && active)  // core.py:226-227
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_kernel(const KParams<T> p
       // and summed with one integer butterfly; only the float rewards need a double butterfly.
       if (want_stats) {
         constexpr int W = 2 * A + 2;
-        constexpr int NW = kSmallThreads / 64;
+        constexpr int NW = THREADS / 64;
         static_assert(A <= 4 && (!TAG || (A - NADV == 1 && NADV <= 3)), "counter packing assumes the stock worlds");
         __shared__ double sred[NW][W];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -70,17 +70,18 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const T sa = d.size[a];
             int b = a + 1;
             if (d.ncol_prefix >= 0) {
-              // regular worlds (all of [0, ncol) collide): 4 independent pair evaluations per trip
+              // regular worlds (all of [0, ncol) collide): U independent pair evaluations per trip
               // for instruction-level parallelism; the additions stay in ascending-b order.
               const int bend = d.ncol_prefix;
-              for (; b + 3 < bend; b += 4) {
-                T fx[4], fy[4];
+              constexpr int U = sizeof(T) == 4 ? 4 : 1;  // f64 pair code is long: unrolling it spills
+              for (; b + U - 1 < bend; b += U) {
+                T fx[U], fy[U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < U; ++u)
                   pair_force<T>(pax - sPos[(2 * (b + u)) * TILE + lane], pay - sPos[(2 * (b + u) + 1) * TILE + lane],
                                 sa + d.size[b + u], d, fx[u], fy[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                   Fx = fx[u] + Fx;
                   Fy = fy[u] + Fy;
                 }

@@ -128,7 +128,7 @@ class MultiAgentEnv(object):
         self.agents = self.world.policy_agents
         if self._fused:
             w = self.world
-            w.gather()
+            w.gather_obs()
             return list(w.obs_views)
         return [self._get_obs(agent) for agent in self.agents]
 

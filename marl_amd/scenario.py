@@ -45,7 +45,7 @@ class HipScenario(BaseScenario):
         world.mark_dirty()
 
     def observation(self, agent, world):
-        world.gather()
+        world.gather_obs()
         return world.obs_views[agent._index]
 
     def reward(self, agent, world):
