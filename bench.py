@@ -11,7 +11,7 @@ statistics accumulated on device and all-reduced (RCCL) once per episode.  Input
 rotating pool of action tensors) are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, fused
-env-step kernel, HIP-event timed per launch inside the timed region) and `cpu_baseline` (the
+env-step kernel, HIP-event brackets around the launches inside the timed region) and `cpu_baseline` (the
 oracle's serial numpy loop on one host core, rank 0 at N=1 only).
 """
 import argparse
@@ -128,21 +128,33 @@ def main():
     stats_total = torch.zeros(2 * n + 2, dtype=torch.float64, device=device)
 
     def run(nsteps, events=None, t_base=0):
+        """events: list collecting (start, end, n_launches) HIP-event brackets around each run of
+        consecutive fused env-step launches (one bracket per episode segment: an event between every
+        pair of launches would itself cost ~5 us of dispatch gap per step)."""
+        open_bracket = None
         for t in range(nsteps):
             tt = t_base + t
             if tt % EPISODE_LEN == 0:
+                if open_bracket is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    events.append((open_bracket[0], e1, open_bracket[1]))
+                    open_bracket = None
                 if tt:
                     stats_total.add_(stats.read())      # deterministic reduce + one all-reduce / episode
                     stats.reset()
                 env.reset()
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if events is not None and open_bracket is None:
+                e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-                env.step(pool[tt % len(pool)])
-                e1.record()
-                events.append((e0, e1))
-            else:
-                env.step(pool[tt % len(pool)])
+                open_bracket = [e0, 0]
+            env.step(pool[tt % len(pool)])
+            if open_bracket is not None:
+                open_bracket[1] += 1
+        if open_bracket is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            events.append((open_bracket[0], e1, open_bracket[1]))
 
     def fence():
         if world_size > 1:
@@ -174,9 +186,9 @@ def main():
     elems = algorithmic_elems(env)
     bytes_per_launch = elems * env.world.pos.element_size() * B
     if events:
-        ms = sorted(a.elapsed_time(b) for a, b in events)
-        kern_ms = sum(ms) / len(ms)
-        kern_med = ms[len(ms) // 2]
+        per = sorted(a.elapsed_time(b) / k for a, b, k in events)
+        kern_ms = sum(a.elapsed_time(b) for a, b, k in events) / sum(k for a, b, k in events)
+        kern_med = per[len(per) // 2]
     else:
         kern_ms = kern_med = elapsed * 1e3 / args.steps
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -202,7 +214,7 @@ def main():
                          'kernel': 'mpe env_step (fused)', 'algorithmic_bytes_per_launch': bytes_per_launch,
                          'bytes_per_env_step': elems * env.world.pos.element_size(),
                          'avg_launch_ms': kern_ms, 'median_launch_ms': kern_med,
-                         'timing': 'hip events per launch' if events else 'wall/steps'},
+                         'timing': 'hip events around each episode segment of consecutive launches / launches' if events else 'wall/steps'},
             'episode_stats': summarize_stats(stats_total, n, EPISODE_LEN),
         }
         if world_size == 1 and not args.no_cpu_baseline:
