@@ -95,6 +95,10 @@ def main():
     ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
     ap.add_argument('--action-buffers', type=int, default=4,
                     help='resident action tensors rotated step by step (1 = the same tensor every step)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the multi-rank path '
+                         'with every rank on whatever GPUs exist (ranks then share devices)')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (roofline from wall time)')
     args = ap.parse_args()
@@ -106,11 +110,15 @@ def main():
         if world_size == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world_size
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank if args.backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     import torch.distributed as dist
     if world_size > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
 
     from marl_amd import make_env
     from marl_amd.distributed import EpisodeStats, shard_range, summarize_stats
@@ -178,7 +186,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stats_total.add_(stats.read())
@@ -207,7 +215,7 @@ def main():
                        'actions': 'softmax(N(0,1)) soft one-hot, %d resident buffers rotated' % len(pool),
                        'reset_in_timed_region': True, 'benchmark_info': True,
                        'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
-                       'parallelism': 'env-sharded dp%d' % world_size},
+                       'parallelism': 'env-sharded dp%d' % world_size, 'backend': args.backend if world_size > 1 else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': measured_traffic(args.workload) if B == envs_per_gpu else None,
@@ -218,7 +226,7 @@ def main():
             'episode_stats': summarize_stats(stats_total, n, EPISODE_LEN),
         }
         if world_size == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_seconds)
         print(json.dumps(out))
     if world_size > 1:
         dist.destroy_process_group()

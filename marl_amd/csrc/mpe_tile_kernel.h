@@ -72,7 +72,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             if (d.ncol_prefix >= 0) {
               // regular worlds (all of [0, ncol) collide): U independent pair evaluations per trip
               // for instruction-level parallelism; the additions stay in ascending-b order.
+#ifdef MPE_ABL_NO_PAIRS
+              const int bend = b + 1 < d.ncol_prefix ? b + 1 : d.ncol_prefix;
+#else
               const int bend = d.ncol_prefix;
+#endif
               constexpr int U = sizeof(T) == 4 ? 4 : 1;  // f64 pair code is long: unrolling it spills
               for (; b + U - 1 < bend; b += U) {
                 T fx[U], fy[U];
@@ -136,7 +140,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
                  want_stats = p.stats != nullptr;
       double *srow = want_stats ? p.stats + (int64_t)blockIdx.x * (2 * A + 2) : nullptr;
       // ---- phase 3a: observations (simple_tag.py:131-147 / simple_spread.py:83-99) -----------------
+#ifdef MPE_ABL_NO_OBS
+      if (p.obs != nullptr && active && p.B < 0) {
+#else
       if (p.obs != nullptr && active) {
+#endif
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
@@ -170,7 +178,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
       }
       __syncthreads();
       // ---- phase 3b: reward / info (sAux aliases sVel from here on) ---------------------------------------------------------------
+#ifdef MPE_ABL_NO_REW
+      if ((want_rew || want_info || want_stats) && p.B < 0) {
+#else
       if (want_rew || want_info || want_stats) {
+#endif
         if (d.kind == MPE_SIMPLE_TAG) {
           // hit(g,a) = is_collision(good g, adversary a) (simple_tag.py:69-73), each pair evaluated
           // once by the chunk that owns g; per-adversary counts meet in LDS (ds_add, rare).
