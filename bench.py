@@ -120,7 +120,9 @@ def main():
         else:
             dist.init_process_group('gloo')
 
-    from marl_amd import make_env
+    from marl_amd import make_env, _hip
+    if os.environ.get('MPE_FORCE_TILE'):      # tuning aid: run the stock worlds on the generic LDS-tile kernel
+        _hip.lib.mpe_debug_force_tile_kernel(1)
     from marl_amd.distributed import EpisodeStats, shard_range, summarize_stats
 
     scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[args.workload]

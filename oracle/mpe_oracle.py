@@ -34,6 +34,10 @@ import numpy as np
 
 SIMPLE_TAG = 0
 SIMPLE_SPREAD = 1
+SIMPLE = 2             # build/lib/multiagent/scenarios/simple.py            
+SIMPLE_ADVERSARY = 3   # build/lib/multiagent/scenarios/simple_adversary.py
+SIMPLE_PUSH = 4        # build/lib/multiagent/scenarios/simple_push.py
+GOAL_KINDS = (SIMPLE_ADVERSARY, SIMPLE_PUSH)   # scenarios with a per-env goal landmark (agent.goal_a)
 
 
 # --------------------------------------------------------------------------------------
@@ -69,6 +73,12 @@ class ScenarioSpec:
         if self.kind == SIMPLE_TAG:
             n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
             return 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others
+        if self.kind == SIMPLE:                 # simple.py:50
+            return 2 + 2 * L
+        if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:137-140
+            return 2 * L + 2 * (A - 1) + (0 if self.adversary[i] else 2)
+        if self.kind == SIMPLE_PUSH:            # simple_push.py:100-104
+            return 2 + 2 * L + 2 * (A - 1) + (0 if self.adversary[i] else 2 + 3 + 3 * L)
         return 4 + 2 * L + 2 * (A - 1) + self.dim_c * (A - 1)
 
     @property
@@ -77,6 +87,10 @@ class ScenarioSpec:
 
     @property
     def info_width(self):
+        if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:58-67 (tuple of L+1 for good agents)
+            return self.n_landmarks + 1
+        if self.kind in (SIMPLE, SIMPLE_PUSH):  # no benchmark_data in these scenarios
+            return 0
         return 1 if self.kind == SIMPLE_TAG else 4
 
 
@@ -106,6 +120,34 @@ def simple_spread_spec(n_agents=3, n_landmarks=3, u_noise=None):
         movable=[True] * A + [False] * n_landmarks,
         u_noise=[u_noise] * A, mass=[1.0] * (A + n_landmarks),
         agent_pos_range=1.0, landmark_pos_range=1.0)
+
+
+def simple_spec():
+    """simple.py:6-22 (World defaults: dim_c = 0, size 0.05, nothing collides)."""
+    return ScenarioSpec(
+        kind=SIMPLE, n_agents=1, n_landmarks=1, adversary=[False], size=[0.05, 0.05],
+        accel=[None], max_speed=[None], collide=[False, False], movable=[True, False],
+        u_noise=[None], mass=[1.0, 1.0], agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=0)
+
+
+def simple_adversary_spec(n_agents=3):
+    """simple_adversary.py:9-34: 1 adversary first, N-1 landmarks, nothing collides."""
+    A, L = n_agents, n_agents - 1
+    return ScenarioSpec(
+        kind=SIMPLE_ADVERSARY, n_agents=A, n_landmarks=L, adversary=[i < 1 for i in range(A)],
+        size=[0.15] * A + [0.08] * L, accel=[None] * A, max_speed=[None] * A,
+        collide=[False] * (A + L), movable=[True] * A + [False] * L,
+        u_noise=[None] * A, mass=[1.0] * (A + L), agent_pos_range=1.0, landmark_pos_range=1.0)
+
+
+def simple_push_spec(n_agents=10, n_adv=9, n_landmarks=1):
+    """simple_push.py:12-39 (this fork's copy: 10 agents, 9 adversaries first, 1 landmark)."""
+    A, L = n_agents, n_landmarks
+    return ScenarioSpec(
+        kind=SIMPLE_PUSH, n_agents=A, n_landmarks=L, adversary=[i < n_adv for i in range(A)],
+        size=[0.05] * (A + L), accel=[None] * A, max_speed=[None] * A,
+        collide=[True] * A + [False] * L, movable=[True] * A + [False] * L,
+        u_noise=[None] * A, mass=[1.0] * (A + L), agent_pos_range=1.0, landmark_pos_range=1.0)
 
 
 # --------------------------------------------------------------------------------------
@@ -142,6 +184,7 @@ class SerialEnv:
         self.agents = self.bodies[:spec.n_agents]
         self.landmarks = self.bodies[spec.n_agents:]
         self.n = spec.n_agents
+        self.goal = 0        # index of the goal landmark (agent.goal_a), GOAL_KINDS only
 
     # -- state helpers ----------------------------------------------------------------
     def set_state(self, pos, vel):
@@ -156,6 +199,8 @@ class SerialEnv:
     # -- reset: simple_tag.py:39-54 / simple_spread.py:30-44 (global np.random stream) --
     def reset(self):
         s = self.spec
+        if s.kind in GOAL_KINDS:   # goal = np.random.choice(world.landmarks) (simple_adversary.py:45)
+            self.goal = int(np.random.choice(len(self.landmarks)))
         for a in self.agents:
             a.pos = np.random.uniform(-s.agent_pos_range, +s.agent_pos_range, 2)
             a.vel = np.zeros(2)
@@ -223,8 +268,37 @@ class SerialEnv:
         d = p.pos - q.pos
         return bool(np.sqrt(np.sum(np.square(d))) < p.size + q.size)
 
+    def _sq(self, p, q):
+        return np.sum(np.square(p.pos - q.pos))
+
+    def _push_colors(self, me):
+        """simple_push.py:43-56: landmark i -> 0.1 with [i+1] += 0.8; good agent -> 0.25 with [goal+1] += 0.5."""
+        lm_colors = []
+        for i in range(len(self.landmarks)):
+            c = np.array([0.1, 0.1, 0.1])
+            c[i + 1] += 0.8
+            lm_colors.append(c)
+        mine = np.array([0.25, 0.25, 0.25])
+        mine[self.goal + 1] += 0.5
+        return mine, lm_colors
+
     def observation(self, i):
         me = self.agents[i]
+        kind = self.spec.kind
+        if kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
+            goal = self.landmarks[self.goal]
+            rel_lm = [lm.pos - me.pos for lm in self.landmarks]
+            rel_ag = [o.pos - me.pos for o in self.agents if o is not me]
+            if kind == SIMPLE:                                   # simple.py:45-50
+                return np.concatenate([me.vel] + rel_lm)
+            if kind == SIMPLE_ADVERSARY:                         # simple_adversary.py:122-140
+                if not me.adversary:
+                    return np.concatenate([goal.pos - me.pos] + rel_lm + rel_ag)
+                return np.concatenate(rel_lm + rel_ag)
+            if not me.adversary:                                 # simple_push.py:84-104
+                mine, lm_colors = self._push_colors(me)
+                return np.concatenate([me.vel] + [goal.pos - me.pos] + [mine] + rel_lm + lm_colors + rel_ag)
+            return np.concatenate([me.vel] + rel_lm + rel_ag)
         rel_lm = [lm.pos - me.pos for lm in self.landmarks]
         rel_ag, tail = [], []
         for j, other in enumerate(self.agents):
@@ -240,6 +314,24 @@ class SerialEnv:
 
     def reward(self, i):
         me = self.agents[i]
+        kind = self.spec.kind
+        if kind == SIMPLE:                                       # simple.py:41-43
+            return -self._sq(me, self.landmarks[0])
+        if kind in GOAL_KINDS:
+            goal = self.landmarks[self.goal]
+            goods = [a for a in self.agents if not a.adversary]
+            advs = [a for a in self.agents if a.adversary]
+            if kind == SIMPLE_ADVERSARY:                         # simple_adversary.py:77-119
+                if me.adversary:
+                    return -self._sq(me, goal)
+                adv_rew = sum([np.sqrt(self._sq(a, goal)) for a in advs])
+                pos_rew = -min([np.sqrt(self._sq(a, goal)) for a in goods])
+                return pos_rew + adv_rew
+            if not me.adversary:                                 # simple_push.py:66-82
+                return -np.sqrt(self._sq(me, goal))
+            pos_rew = min([np.sqrt(self._sq(a, goal)) for a in goods])
+            neg_rew = np.sqrt(np.sum(np.square(goal.pos - me.pos)))
+            return pos_rew - neg_rew
         if self.spec.kind == SIMPLE_TAG:
             advs = [a for a in self.agents if a.adversary]
             goods = [a for a in self.agents if not a.adversary]
@@ -276,6 +368,13 @@ class SerialEnv:
 
     def info(self, i):
         me = self.agents[i]
+        if self.spec.kind == SIMPLE_ADVERSARY:                   # simple_adversary.py:58-67
+            goal = self.landmarks[self.goal]
+            if me.adversary:
+                return self._sq(me, goal)
+            return tuple([self._sq(me, lm) for lm in self.landmarks] + [self._sq(me, goal)])
+        if self.spec.kind in (SIMPLE, SIMPLE_PUSH):
+            return {}
         if self.spec.kind == SIMPLE_TAG:           # simple_tag.py:57-66
             if not me.adversary:
                 return 0
@@ -304,7 +403,7 @@ class SerialEnv:
             obs_n.append(self.observation(i))
             rew_n.append(self.reward(i))
             done_n.append(False)
-            info_n['n'].append(self.info(i) if self.benchmark else {})
+            info_n['n'].append(self.info(i) if self.benchmark and self.spec.info_width else {})
         return obs_n, rew_n, done_n, info_n
 
 
@@ -366,13 +465,77 @@ class BatchedOracle:
         d = pos[i] - pos[j]
         return np.sqrt(np.square(d[0]) + np.square(d[1]))
 
-    def observe(self, pos, vel, want_info=True):
+    def _observe_f1(self, pos, vel, goal):
+        """simple / simple_adversary / simple_push gathers."""
+        s, T = self.spec, self.dt
+        A, L = s.n_agents, s.n_landmarks
+        B = pos.shape[-1]
+        goal = np.zeros(B, np.int64) if goal is None else np.asarray(goal, np.int64)
+        gp = pos[A:][goal, :, np.arange(B)].T                   # goal landmark position [2,B]
+        sq = lambda p, q: np.square(p[0] - q[0]) + np.square(p[1] - q[1])
+        advs = [i for i in range(A) if s.adversary[i]]
+        goods = [i for i in range(A) if not s.adversary[i]]
+        obs, rew = [], np.zeros((A, B), T)
+        info = np.zeros((A, s.info_width, B), T)
+        for i in range(A):
+            rel_lm = [pos[A + l] - pos[i] for l in range(L)]
+            rel_ag = [pos[j] - pos[i] for j in range(A) if j != i]
+            if s.kind == SIMPLE:
+                rows = [vel[i]] + rel_lm
+            elif s.kind == SIMPLE_ADVERSARY:
+                rows = ([] if s.adversary[i] else [gp - pos[i]]) + rel_lm + rel_ag
+            elif s.adversary[i]:
+                rows = [vel[i]] + rel_lm + rel_ag
+            else:
+                mine = np.full((3, B), 0.25, T)
+                mine[goal + 1, np.arange(B)] += T(0.5)
+                lmc = []
+                for l in range(L):
+                    c = np.full((3, B), 0.1, T)
+                    c[l + 1] += T(0.8)
+                    lmc.append(c)
+                rows = [vel[i], gp - pos[i], mine] + rel_lm + lmc + rel_ag
+            obs.append(np.concatenate(rows, axis=0))
+        with np.errstate(all='ignore'):
+            if s.kind == SIMPLE:
+                rew[0] = -sq(pos[0], pos[A])
+            elif s.kind == SIMPLE_ADVERSARY:
+                adv_rew = 0
+                for a in advs:
+                    adv_rew = adv_rew + np.sqrt(sq(pos[a], gp))
+                m = np.sqrt(sq(pos[goods[0]], gp))
+                for g in goods[1:]:
+                    m = np.minimum(m, np.sqrt(sq(pos[g], gp)))
+                for i in range(A):
+                    if s.adversary[i]:
+                        rew[i] = -sq(pos[i], gp)
+                        info[i, 0] = sq(pos[i], gp)
+                    else:
+                        rew[i] = -m + adv_rew
+                        for l in range(L):
+                            info[i, l] = sq(pos[i], pos[A + l])
+                        info[i, L] = sq(pos[i], gp)
+            else:
+                m = np.sqrt(sq(pos[goods[0]], gp))
+                for g in goods[1:]:
+                    m = np.minimum(m, np.sqrt(sq(pos[g], gp)))
+                for i in range(A):
+                    if s.adversary[i]:
+                        rew[i] = m - np.sqrt(sq(gp, pos[i]))
+                    else:
+                        rew[i] = -np.sqrt(sq(pos[i], gp))
+        return obs, rew, info
+
+    def observe(self, pos, vel, want_info=True, goal=None):
         """Returns obs (list of [dim_i, B]), rew [A,B], info [A,W,B]."""
         s, T = self.spec, self.dt
         A, L, E = s.n_agents, s.n_landmarks, s.n_entities
         B = pos.shape[-1]
         pos = np.asarray(pos, dtype=T)
         vel = np.asarray(vel, dtype=T)
+        if s.kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
+            obs, rew, info = self._observe_f1(pos, vel, goal)
+            return obs, rew, (info if want_info else None)
         obs = []
         for i in range(A):
             rows = [vel[i], pos[i]]
@@ -430,9 +593,9 @@ class BatchedOracle:
                     info[i, 0], info[i, 1], info[i, 2], info[i, 3] = r, c, md, occ
         return obs, rew, (info if want_info else None)
 
-    def env_step(self, pos, vel, act, noise=None):
+    def env_step(self, pos, vel, act, noise=None, goal=None):
         pos, vel = self.world_step(pos, vel, act, noise)
-        obs, rew, info = self.observe(pos, vel)
+        obs, rew, info = self.observe(pos, vel, goal=goal)
         return pos, vel, obs, rew, info
 
 

@@ -16,6 +16,7 @@ Cases:
   G5  dense starts U(-0.3, 0.3): collisions / max_speed clamp / +-10 rewards fire
       (tag and spread)
   G6  out-of-bounds starts: all four branches of simple_tag bound()
+  G7-G9 simple / simple_adversary / simple_push, default and dense starts
   KAT known-answer cases 1, 2, 4 of SURVEY.md section 8c
 
 Run:  python tests/golden/gen_golden.py
@@ -74,6 +75,8 @@ from multiagent.core import World, Agent, Landmark  # noqa: E402  (reference)
 
 TAG = _load(REF + '/build/lib/multiagent/scenarios/simple_tag.py', 'ref_simple_tag')
 SPREAD = _load(REF + '/build/lib/multiagent/scenarios/simple_spread.py', 'ref_simple_spread')
+OTHER = {k: _load(REF + '/build/lib/multiagent/scenarios/%s.py' % k, 'ref_' + k)
+         for k in ('simple', 'simple_adversary', 'simple_push')}
 
 
 def _shim(world):
@@ -111,14 +114,17 @@ def build_env(kind, seed, scaled=None, u_noise=None):
                 lm.size = 0.2
                 lm.boundary = False
             S.reset_world(world)
-    else:
+    elif kind == 'simple_spread':
         S = SPREAD.Scenario()
+        world = S.make_world()
+    else:
+        S = OTHER[kind].Scenario()
         world = S.make_world()
     _shim(world)
     if u_noise is not None:
         for a in world.agents:
             a.u_noise = u_noise
-    env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data)
+    env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, getattr(S, 'benchmark_data', None))
     return env, world
 
 
@@ -128,13 +134,23 @@ def _state(world):
     return pos, vel
 
 
-def _info_row(x):
-    return np.atleast_1d(np.asarray(x, dtype=np.float64))
+def _info_row(x, width=None):
+    if isinstance(x, dict):                       # no benchmark_data callback (environment.py:133-134)
+        return np.zeros(0)
+    r = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    if width is not None and r.shape[0] < width:  # simple_adversary: scalar for the adversary, tuple for the others
+        r = np.concatenate([r, np.zeros(width - r.shape[0])])
+    return r
+
+
+def _goal_index(world):
+    g = getattr(world.agents[0], 'goal_a', None)
+    return -1 if g is None else world.landmarks.index(g)
 
 
 def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'):
     """Returns dict of stacked arrays over seeds."""
-    keys = ('pos0', 'vel0', 'obs0', 'act', 'noise', 'pos', 'vel', 'obs', 'rew', 'info')
+    keys = ('pos0', 'vel0', 'obs0', 'goal', 'act', 'noise', 'pos', 'vel', 'obs', 'rew', 'info')
     out = {k: [] for k in keys}
     for seed in seeds:
         env, world = build_env(kind, seed, scaled, u_noise)
@@ -144,6 +160,7 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
             init(world, np.random.RandomState(10_000 + seed))
             obs0 = [env._get_obs(a) for a in env.agents]
         pos0, vel0 = _state(world)
+        out['goal'].append(_goal_index(world))
         arng = np.random.RandomState(20_000 + seed)
         ep = {k: [] for k in ('act', 'noise', 'pos', 'vel', 'obs', 'rew', 'info')}
         for t in range(T):
@@ -167,13 +184,15 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
             ep['vel'].append(vel.copy())
             ep['obs'].append(np.concatenate(obs_n))
             ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
-            ep['info'].append(np.stack([_info_row(x) for x in info_n['n']]))
+            rows = [_info_row(x) for x in info_n['n']]
+            width = max(r.shape[0] for r in rows)
+            ep['info'].append(np.stack([_info_row(x, width) for x in info_n['n']]))
         out['pos0'].append(pos0)
         out['vel0'].append(vel0)
         out['obs0'].append(np.concatenate(obs0))
         for k in ep:
             out[k].append(np.stack(ep[k]))
-    res = {k: np.stack(v) for k, v in out.items()}
+    res = {k: (np.asarray(v) if k == 'goal' else np.stack(v)) for k, v in out.items()}
     res['seeds'] = np.asarray(list(seeds))
     res['u_noise'] = np.float64(0.0 if u_noise is None else u_noise)
     if u_noise is None:
@@ -253,6 +272,14 @@ def main():
                                              actions='softmax'))
     save('g6_simple_tag_oob', **rollout('simple_tag', range(24), 10, init=oob_init,
                                         actions='rand'))
+    # the remaining all-silent stock scenarios (same physics, new gathers)
+    save('g7_simple', **rollout('simple', range(32), 25))
+    save('g8_simple_adversary', **rollout('simple_adversary', range(48), 25))
+    save('g8_simple_adversary_dense', **rollout('simple_adversary', range(16), 25, init=dense_init,
+                                                actions='softmax'))
+    save('g9_simple_push', **rollout('simple_push', range(24), 25))
+    save('g9_simple_push_dense', **rollout('simple_push', range(16), 25, init=dense_init,
+                                           actions='softmax'))
     kat_cases()
 
 

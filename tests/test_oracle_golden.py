@@ -17,6 +17,11 @@ CASES = [
     ('g5_simple_tag_dense', lambda: O.simple_tag_spec()),
     ('g5_simple_spread_dense', lambda: O.simple_spread_spec()),
     ('g6_simple_tag_oob', lambda: O.simple_tag_spec()),
+    ('g7_simple', lambda: O.simple_spec()),
+    ('g8_simple_adversary', lambda: O.simple_adversary_spec()),
+    ('g8_simple_adversary_dense', lambda: O.simple_adversary_spec()),
+    ('g9_simple_push', lambda: O.simple_push_spec()),
+    ('g9_simple_push_dense', lambda: O.simple_push_spec()),
 ]
 
 
@@ -49,6 +54,7 @@ def test_serial_oracle_bit_exact(golden_dir, name, mk, monkeypatch):
     for s in range(n_serial):
         env = O.SerialEnv(spec, benchmark=True)
         env.set_state(g['pos0'][s], g['vel0'][s])
+        env.goal = max(int(g['goal'][s]), 0)
         assert np.array_equal(np.concatenate([env.observation(i) for i in range(env.n)]), g['obs0'][s])
         for t in range(n_steps):
             if 'noise' in g.files:
@@ -59,7 +65,9 @@ def test_serial_oracle_bit_exact(golden_dir, name, mk, monkeypatch):
             assert np.array_equal(vel, g['vel'][s, t]), (name, s, t)
             assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
             assert np.array_equal(np.asarray(rew_n, float), g['rew'][s, t]), (name, s, t)
-            info = np.stack([np.atleast_1d(np.asarray(x, float)) for x in info_n['n']])
+            W = spec.info_width
+            info = np.stack([np.concatenate([np.atleast_1d(np.asarray(x, float)), np.zeros(W)])[:W]
+                             if not isinstance(x, dict) else np.zeros(0) for x in info_n['n']])
             assert np.array_equal(info, g['info'][s, t]), (name, s, t)
             assert done_n == [False] * env.n
 
@@ -73,12 +81,13 @@ def test_batched_oracle_bit_exact(golden_dir, name, mk):
     bo = O.BatchedOracle(spec, np.float64)
     pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))   # [E,2,S]
     vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
-    obs, _, _ = bo.observe(pos, vel)
+    goal = np.maximum(g['goal'], 0)
+    obs, _, _ = bo.observe(pos, vel, goal=goal)
     assert np.array_equal(np.concatenate(obs, 0), g['obs0'].T)
     for t in range(T):
         act = np.moveaxis(g['act'][:, t], 0, -1)                 # [A,5,S]
         noise = np.moveaxis(g['noise'][:, t], 0, -1) if 'noise' in g.files else None
-        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, noise)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, noise, goal=goal)
         assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), (name, t)
         assert np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1)), (name, t)
         assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
@@ -153,7 +162,9 @@ def test_kat4_far_apart_zero_action(golden_dir):
 def test_serial_reset_uses_reference_draw_order(golden_dir):
     """np.random.seed(s); make_world (one reset) ; env.reset() -> same pos0 as the reference
     (agents ascending then landmarks ascending, 2 uniforms each: simple_tag.py:47-54)."""
-    for name, spec in (('g1_simple_tag', O.simple_tag_spec()), ('g2_simple_spread', O.simple_spread_spec())):
+    for name, spec in (('g1_simple_tag', O.simple_tag_spec()), ('g2_simple_spread', O.simple_spread_spec()),
+                       ('g7_simple', O.simple_spec()), ('g8_simple_adversary', O.simple_adversary_spec()),
+                       ('g9_simple_push', O.simple_push_spec())):
         g = _load(golden_dir, name)
         for s in g['seeds'][:8]:
             np.random.seed(int(s))
@@ -163,6 +174,8 @@ def test_serial_reset_uses_reference_draw_order(golden_dir):
             pos, vel = env.get_state()
             assert np.array_equal(pos, g['pos0'][s]) and np.array_equal(vel, g['vel0'][s])
             assert np.array_equal(np.concatenate(obs), g['obs0'][s])
+            if spec.kind in O.GOAL_KINDS:       # goal = np.random.choice(world.landmarks) drawn first
+                assert env.goal == g['goal'][s]
 
 
 def test_philox_known_answers():
