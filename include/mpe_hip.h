@@ -26,8 +26,13 @@
  *                              may be NULL (then not written)
  *         obs  [obs_total][ld]  agent i owns rows [obs_row0(i), obs_row0(i)+obs_dim(i))
  *         rew  [A][ld]
- *         info [A][info_w][ld]  info_w = 1 (simple_tag: collisions) or 4 (simple_spread:
- *                               rew, collisions, min_dists, occupied_landmarks); may be NULL
+ *         info [A][info_w][ld]  info_w = 1 (simple_tag: collisions), 4 (simple_spread:
+ *                               rew, collisions, min_dists, occupied_landmarks), L+1
+ *                               (simple_adversary: squared distances; the adversary uses column
+ *                               0 only) or 0 (simple, simple_push: no benchmark_data); may be NULL
+ *         goal [ld] int32       index of the goal landmark (agent.goal_a, simple_adversary.py:45-48
+ *                               / simple_push.py:48-50); required for those two kinds, ignored
+ *                               (may be NULL) otherwise
  *     `B` = number of envs processed, `ld` = row stride in elements (ld >= B), so a sub-range of a
  *     larger batch can be processed by offsetting the pointers.
  *   - _f32 / _f64 = arithmetic (and storage) type of the path.  f64 follows the reference's
@@ -43,13 +48,16 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 1
+#define MPE_ABI_VERSION 2
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
 /* scenario kinds (which observation/reward/info gather runs) */
 #define MPE_SIMPLE_TAG 0    /* build/lib/multiagent/scenarios/simple_tag.py    */
 #define MPE_SIMPLE_SPREAD 1 /* build/lib/multiagent/scenarios/simple_spread.py */
+#define MPE_SIMPLE 2        /* build/lib/multiagent/scenarios/simple.py            */
+#define MPE_SIMPLE_ADVERSARY 3 /* build/lib/multiagent/scenarios/simple_adversary.py (per-env goal) */
+#define MPE_SIMPLE_PUSH 4   /* build/lib/multiagent/scenarios/simple_push.py      (per-env goal) */
 
 /* error codes */
 #define MPE_OK 0
@@ -66,7 +74,7 @@ extern "C" {
  * call only.  Entities are indexed agents first, then landmarks.
  */
 typedef struct mpe_scenario_desc {
-  int32_t kind;        /* MPE_SIMPLE_TAG / MPE_SIMPLE_SPREAD */
+  int32_t kind;        /* MPE_SIMPLE_TAG / _SPREAD / MPE_SIMPLE / _ADVERSARY / _PUSH */
   int32_t n_agents;    /* A, 1..MPE_MAX_AGENTS */
   int32_t n_landmarks; /* L, A+L <= MPE_MAX_ENTITIES */
   int32_t dim_c;       /* world.dim_c (comm width; 2 in both scenarios) */
@@ -118,14 +126,17 @@ int mpe_world_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, con
 /*
  * Scenario gathers from the current state, for every agent of every env:
  * observation (simple_tag.py:131-147 / simple_spread.py:83-99), reward (simple_tag.py:84-129 /
- * simple_spread.py:71-81), benchmark_data (simple_tag.py:57-66 / simple_spread.py:46-62).
+ * simple_spread.py:71-81), benchmark_data (simple_tag.py:57-66 / simple_spread.py:46-62); for the
+ * other kinds simple.py:41-50, simple_adversary.py:58-140, simple_push.py:66-104.
  * Any of obs / rew / info may be NULL (skipped); MultiAgentEnv.reset() needs obs only
  * (environment.py:119-129).
  */
 int mpe_observe_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *pos,
-                    const float *vel, float *obs, float *rew, float *info, void *stream);
+                    const float *vel, const int32_t *goal, float *obs, float *rew, float *info,
+                    void *stream);
 int mpe_observe_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *pos,
-                    const double *vel, double *obs, double *rew, double *info, void *stream);
+                    const double *vel, const int32_t *goal, double *obs, double *rew, double *info,
+                    void *stream);
 
 /*
  * MultiAgentEnv.step (environment.py:92-117) in one launch: mpe_world_step followed by
@@ -135,11 +146,12 @@ int mpe_observe_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const 
  * mpe_stats_reduce.  Zero it with hipMemsetAsync before the first step of a window.
  */
 int mpe_env_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *act,
-                     const float *noise, float *pos, float *vel, float *comm, float *obs,
-                     float *rew, float *info, double *stats, void *stream);
+                     const float *noise, float *pos, float *vel, float *comm, const int32_t *goal,
+                     float *obs, float *rew, float *info, double *stats, void *stream);
 int mpe_env_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *act,
-                     const double *noise, double *pos, double *vel, double *comm, double *obs,
-                     double *rew, double *info, double *stats, void *stream);
+                     const double *noise, double *pos, double *vel, double *comm,
+                     const int32_t *goal, double *obs, double *rew, double *info, double *stats,
+                     void *stream);
 
 /*
  * Scenario.reset_world (simple_tag.py:39-54 / simple_spread.py:30-44): agents ~ U(-ra, ra)^2,
@@ -147,20 +159,23 @@ int mpe_env_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const
  * np.random stream; this build draws Philox4x32-10 with counter (env_id_lo, env_id_hi, episode,
  * entity) and key = seed, env_id = env_id0 + index, so results do not depend on how envs are
  * sharded over GPUs.  `mask` (may be NULL): uint8 [B], only envs with mask != 0 are reset.
+ * `goal` (may be NULL): the goal landmark of each env is drawn uniformly from the same stream
+ * (entity word 0xFFFFFFFF; np.random.choice(world.landmarks) in the reference).
  */
 int mpe_reset_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
                   uint32_t episode, uint64_t env_id0, const uint8_t *mask, float *pos, float *vel,
-                  float *comm, void *stream);
+                  float *comm, int32_t *goal, void *stream);
 int mpe_reset_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
                   uint32_t episode, uint64_t env_id0, const uint8_t *mask, double *pos,
-                  double *vel, double *comm, void *stream);
+                  double *vel, double *comm, int32_t *goal, void *stream);
 
 /*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,
  * experiments/simple_train.py:284-286, and info_n per agent, :357).  Width = 2*A + 2 doubles:
  * [0,A) sum of reward per agent, [A,2A) sum of collisions per agent (info column 0 for
- * simple_tag, column 1 for simple_spread), [2A] sum over envs of colliding (good,adversary) pairs
- * (simple_tag) or occupied landmarks (simple_spread), [2A+1] number of env-steps.
+ * simple_tag, column 1 for simple_spread, 0 for the other kinds), [2A] sum over envs of colliding
+ * (good,adversary) pairs (simple_tag) or occupied landmarks (simple_spread), [2A+1] number of
+ * env-steps.
  * mpe_stats_rows = number of per-workgroup rows mpe_env_step_* accumulates into for this (desc,
  * B, dtype): dtype_bytes is 4 or 8.  mpe_stats_reduce sums the rows in a fixed order (bitwise
  * reproducible) into out[width]; that vector is what ranks all-reduce over RCCL.
@@ -171,7 +186,8 @@ int mpe_stats_reduce(const double *stats, int64_t rows, int width, double *out, 
 
 /*
  * Test hook (no reference counterpart): on != 0 routes the stock worlds (simple_tag 3+1/2,
- * simple_spread 3/3), which normally run the register-resident kernel, through the generic
+ * simple_spread 3/3, simple 1/1, simple_adversary 3/2, simple_push 10/1), which normally run the
+ * register-resident kernel, through the generic
  * LDS-tile kernel as well, so both kernels can be checked against the same golden vectors.
  * Process-wide; not for production use.
  */

@@ -16,7 +16,11 @@ MPE_MAX_AGENTS = 64
 MPE_MAX_ENTITIES = 128
 MPE_SIMPLE_TAG = 0
 MPE_SIMPLE_SPREAD = 1
-ABI_VERSION = 1
+MPE_SIMPLE = 2
+MPE_SIMPLE_ADVERSARY = 3
+MPE_SIMPLE_PUSH = 4
+GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH)
+ABI_VERSION = 2
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -66,12 +70,12 @@ def _load():
     for suf in ('f32', 'f64'):
         f = getattr(L, 'mpe_world_step_' + suf)
         f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp]
-        f = getattr(L, 'mpe_observe_' + suf)
-        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp]
-        f = getattr(L, 'mpe_env_step_' + suf)
-        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-        f = getattr(L, 'mpe_reset_' + suf)
-        f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_observe_' + suf)          # desc, B, ld, pos, vel, goal, obs, rew, info, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_env_step_' + suf)         # ..., act, noise, pos, vel, comm, goal, obs, rew, info, stats, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_reset_' + suf)            # ..., seed, episode, env_id0, mask, pos, vel, comm, goal, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, vp, vp, vp, vp, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci]
     L.mpe_stats_reduce.restype = ci

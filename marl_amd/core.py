@@ -143,6 +143,7 @@ class World(object):
         self.device = None
         self.dtype = None
         self.pos = self.vel = self.comm = self.act = self.noise = None
+        self.goal = None           # int32 [B]: goal landmark index (agent.goal_a), goal scenarios only
         # gather outputs (allocated on first use): obs [obs_total,B], rew [A,B], info [A,W,B]
         self.obs = self.rew = self.info = None
         self.obs_views = None
@@ -189,6 +190,7 @@ class World(object):
         self.vel = torch.zeros(A, 2, B, **z)
         self.comm = torch.zeros(A, max(self.dim_c, 1), B, **z)[:, :self.dim_c]
         self.act = torch.zeros(A, 5, B, **z)
+        self.goal = torch.zeros(B, dtype=torch.int32, device=device)
         self.noise = None
         self.obs = self.rew = self.info = self.obs_views = self.stats = None
         for i, e in enumerate(self.entities):
@@ -223,7 +225,8 @@ class World(object):
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
         _hip.check(fn(d, self.num_envs, self.num_envs, self.pos.data_ptr(), self.vel.data_ptr(),
-                      self.obs.data_ptr(), None, None, _hip.stream_of(self.device)), 'mpe_observe')
+                      self.goal.data_ptr(), self.obs.data_ptr(), None, None, _hip.stream_of(self.device)),
+                   'mpe_observe')
         self._obs_tick = self._tick
 
     def gather(self, force=False):
@@ -236,7 +239,8 @@ class World(object):
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
         _hip.check(fn(d, self.num_envs, self.num_envs, self.pos.data_ptr(), self.vel.data_ptr(),
-                      self.obs.data_ptr(), self.rew.data_ptr(), self.info.data_ptr(),
+                      self.goal.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
+                      self.info.data_ptr() if self.info.numel() else None,
                       _hip.stream_of(self.device)), 'mpe_observe')
         self._gather_tick = self._tick
 
@@ -268,8 +272,8 @@ class World(object):
         keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_env_step_' + _hip.suffix(self.dtype))
         _hip.check(fn(d, self.num_envs, self.num_envs, self.act.data_ptr(), nptr, self.pos.data_ptr(),
-                      self.vel.data_ptr(), None, self.obs.data_ptr(), self.rew.data_ptr(),
-                      self.info.data_ptr() if want_info else None, _hip.ptr(self.stats),
+                      self.vel.data_ptr(), None, self.goal.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
+                      self.info.data_ptr() if (want_info and self.info.numel()) else None, _hip.ptr(self.stats),
                       _hip.stream_of(self.device)), 'mpe_env_step')
         self._tick += 1
         if want_info:

@@ -36,6 +36,7 @@ struct DevDesc {
 template <typename T>
 struct KParams {
   const T *act, *noise;
+  const int32_t *goal;  // per-env goal landmark index (simple_adversary / simple_push), else unused
   T *pos, *vel, *comm, *obs, *rew, *info;
   double *stats;
   int64_t B, ld;
@@ -167,6 +168,17 @@ __device__ __forceinline__ void integrate_vel_sel(T &vx, T &vy, T Fx, T Fy, T ma
     vx = clamp ? cx : vx;
     vy = clamp ? cy : vy;
   }
+}
+
+// np.sum(np.square(p - q)) for 2-vectors.
+template <typename T>
+__device__ __forceinline__ T sqdist(T px, T py, T qx, T qy) {
+  const T dx = px - qx, dy = py - qy;
+  return dx * dx + dy * dy;
+}
+
+__device__ __forceinline__ bool kind_has_goal(int kind) {
+  return kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH;
 }
 
 // is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): strict <.

@@ -25,7 +25,25 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
       if (j != i && !h->adversary[j]) ++good_others;
     return 4 + 2 * L + 2 * (A - 1) + 2 * good_others;
   }
+  if (h->kind == MPE_SIMPLE) return 2 + 2 * L;  // simple.py:50
+  if (h->kind == MPE_SIMPLE_ADVERSARY)          // simple_adversary.py:137-140
+    return 2 * L + 2 * (A - 1) + (h->adversary[i] ? 0 : 2);
+  if (h->kind == MPE_SIMPLE_PUSH)               // simple_push.py:100-104
+    return 2 + 2 * L + 2 * (A - 1) + (h->adversary[i] ? 0 : 2 + 3 + 3 * L);
   return 4 + 2 * L + 2 * (A - 1) + h->dim_c * (A - 1);  // simple_spread.py:99
+}
+
+static bool kind_has_roles(int kind) {
+  return kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH;
+}
+static bool kind_has_goal(int kind) { return kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH; }
+static int info_width_of(const mpe_scenario_desc *h) {
+  switch (h->kind) {
+    case MPE_SIMPLE_TAG: return 1;
+    case MPE_SIMPLE_SPREAD: return 4;
+    case MPE_SIMPLE_ADVERSARY: return h->n_landmarks + 1;  // simple_adversary.py:58-67
+    default: return 0;                                     // simple.py / simple_push.py: no benchmark_data
+  }
 }
 
 extern "C" int mpe_abi_version(void) { return MPE_ABI_VERSION; }
@@ -46,7 +64,7 @@ extern "C" const char *mpe_strerror(int code) {
 
 extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   if (!h) return MPE_ERR_NULL;
-  if (h->kind != MPE_SIMPLE_TAG && h->kind != MPE_SIMPLE_SPREAD) return MPE_ERR_UNSUPPORTED;
+  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_SIMPLE_PUSH) return MPE_ERR_UNSUPPORTED;
   if (h->n_agents < 1 || h->n_agents > MPE_MAX_AGENTS) return MPE_ERR_DESC;
   if (h->n_landmarks < 0 || h->n_agents + h->n_landmarks > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
   if (h->dim_c < 0 || h->dim_c > 16) return MPE_ERR_DESC;
@@ -61,6 +79,14 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   for (int a = 0; a < h->n_agents; ++a)
     if (!std::isfinite(h->accel[a]) || std::isnan(h->max_speed[a]) || !std::isfinite(h->u_noise[a]))
       return MPE_ERR_DESC;
+  if (h->kind == MPE_SIMPLE && h->n_landmarks < 1) return MPE_ERR_DESC;
+  if (kind_has_goal(h->kind)) {  // a goal landmark and at least one good agent must exist
+    int goods = 0;
+    for (int a = 0; a < h->n_agents; ++a) goods += h->adversary[a] ? 0 : 1;
+    if (h->n_landmarks < 1 || goods < 1) return MPE_ERR_DESC;
+    // simple_push colours index a 3-vector with [goal + 1] (simple_push.py:45,56)
+    if (h->kind == MPE_SIMPLE_PUSH && h->n_landmarks > 2) return MPE_ERR_DESC;
+  }
   return MPE_OK;
 }
 
@@ -88,7 +114,7 @@ extern "C" int mpe_obs_total(const mpe_scenario_desc *h) {
 extern "C" int mpe_info_width(const mpe_scenario_desc *h) {
   int rc = mpe_desc_check(h);
   if (rc) return rc;
-  return h->kind == MPE_SIMPLE_TAG ? 1 : 4;
+  return info_width_of(h);
 }
 extern "C" int mpe_stats_width(const mpe_scenario_desc *h) {
   int rc = mpe_desc_check(h);
@@ -104,7 +130,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
   d.L = h->n_landmarks;
   d.E = d.A + d.L;
   d.dim_c = h->dim_c;
-  d.info_w = h->kind == MPE_SIMPLE_TAG ? 1 : 4;
+  d.info_w = info_width_of(h);
   d.dt = (T)h->dt;
   d.damp1 = (T)(1 - h->damping);  // core.py:214: (1 - self.damping) evaluated in float64
   d.cforce = (T)h->contact_force;
@@ -121,7 +147,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     d.accel[a] = (T)h->accel[a];
     d.max_speed[a] = (T)h->max_speed[a];
     d.u_noise[a] = (T)h->u_noise[a];
-    if (h->kind == MPE_SIMPLE_TAG && h->adversary[a]) {
+    if (kind_has_roles(h->kind) && h->adversary[a]) {
       d.adversary[a >> 5] |= 1u << (a & 31);
       d.adv_list[d.n_adv++] = (uint8_t)a;
     } else {
@@ -141,25 +167,46 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
 // ------------------------------------------------------------------------------------------------
 // kernel selection
 // ------------------------------------------------------------------------------------------------
-enum SmallId { SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3 };
+enum SmallId { SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3, SMALL_SIMPLE_1_1, SMALL_ADVERSARY_3_2, SMALL_PUSH_10_1 };
 
-// The register kernel hard-codes the stock role flags (mpe_small_kernel.h); anything else -> tile kernel.
+// The register kernel hard-codes the stock shapes and role flags (mpe_small_kernel.h: which
+// entities collide, who has a max_speed, adversaries first); anything else -> tile kernel.
 static SmallId small_variant(const mpe_scenario_desc *h) {
   const int A = h->n_agents, L = h->n_landmarks;
-  const bool tag = h->kind == MPE_SIMPLE_TAG;
-  if (!((tag && A == 4 && L == 2) || (!tag && A == 3 && L == 3))) return SMALL_NONE;
-  for (int a = 0; a < A; ++a) {
-    if (!h->movable[a] || !h->collide[a]) return SMALL_NONE;
-    if (tag ? !(h->max_speed[a] >= 0.0) : (h->max_speed[a] >= 0.0)) return SMALL_NONE;
-    if (tag && (h->adversary[a] != 0) != (a < 3)) return SMALL_NONE;
+  SmallId id;
+  int nadv, ecol;       // adversaries (first nadv agents), leading colliding entities
+  bool has_max;
+  switch (h->kind) {
+    case MPE_SIMPLE_TAG: id = SMALL_TAG_3_1_2; if (A != 4 || L != 2) return SMALL_NONE; nadv = 3; ecol = 6; has_max = true; break;
+    case MPE_SIMPLE_SPREAD: id = SMALL_SPREAD_3_3; if (A != 3 || L != 3) return SMALL_NONE; nadv = 0; ecol = 3; has_max = false; break;
+    case MPE_SIMPLE: id = SMALL_SIMPLE_1_1; if (A != 1 || L != 1) return SMALL_NONE; nadv = 0; ecol = 0; has_max = false; break;
+    case MPE_SIMPLE_ADVERSARY: id = SMALL_ADVERSARY_3_2; if (A != 3 || L != 2) return SMALL_NONE; nadv = 1; ecol = 0; has_max = false; break;
+    case MPE_SIMPLE_PUSH: id = SMALL_PUSH_10_1; if (A != 10 || L != 1) return SMALL_NONE; nadv = 9; ecol = 10; has_max = false; break;
+    default: return SMALL_NONE;
   }
-  for (int e = A; e < A + L; ++e)
-    if ((h->collide[e] != 0) != tag) return SMALL_NONE;
-  return tag ? SMALL_TAG_3_1_2 : SMALL_SPREAD_3_3;
+  for (int a = 0; a < A; ++a) {
+    if (!h->movable[a]) return SMALL_NONE;
+    if ((h->max_speed[a] >= 0.0) != has_max) return SMALL_NONE;
+    if (h->kind != MPE_SIMPLE_SPREAD && h->kind != MPE_SIMPLE && (h->adversary[a] != 0) != (a < nadv)) return SMALL_NONE;
+  }
+  for (int e = 0; e < A + L; ++e)
+    if ((h->collide[e] != 0) != (e < ecol)) return SMALL_NONE;
+  return id;
 }
 
 static bool g_force_tile = false;  // test hook: route the stock worlds through the tile kernel too
 extern "C" void mpe_debug_force_tile_kernel(int on) { g_force_tile = on != 0; }
+
+// Workgroup size of the register kernel for this launch, or 0 = use the tile kernel.
+// simple_push (10 agents) needs ~164 VGPRs in f32 (no 1024-lane workgroups) and > 256 in f64
+// (register kernel would spill: the tile kernel takes it).
+static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, SmallId *out) {
+  const SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
+  if (out) *out = sv;
+  if (sv == SMALL_NONE) return 0;
+  if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
+  return small_threads(B, dtype_bytes);
+}
 
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
@@ -186,23 +233,33 @@ static int launch_small(const KParams<T> &p, bool noise, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
+static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) {
+  switch (sv) {
+    case SMALL_TAG_3_1_2: return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, THREADS, DO_STEP, DO_OBS>(p, noise, s);
+    case SMALL_SPREAD_3_3: return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, THREADS, DO_STEP, DO_OBS>(p, noise, s);
+    case SMALL_SIMPLE_1_1: return launch_small<T, MPE_SIMPLE, 1, 1, 0, THREADS, DO_STEP, DO_OBS>(p, noise, s);
+    case SMALL_ADVERSARY_3_2: return launch_small<T, MPE_SIMPLE_ADVERSARY, 3, 2, 1, THREADS, DO_STEP, DO_OBS>(p, noise, s);
+    case SMALL_PUSH_10_1:
+      if constexpr (sizeof(T) == 4 && THREADS == kSmallThreads)
+        return launch_small<T, MPE_SIMPLE_PUSH, 10, 1, 9, THREADS, DO_STEP, DO_OBS>(p, noise, s);
+      return MPE_ERR_UNSUPPORTED;
+    default: return MPE_ERR_UNSUPPORTED;
+  }
+}
+
 template <typename T, bool DO_STEP, bool DO_OBS>
 static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
-  const SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
-  if (sv != SMALL_NONE) {
+  SmallId sv;
+  const int threads = small_launch_threads(h, p.B, (int)sizeof(T), &sv);
+  if (threads != 0) {
     bool noise = false;
     if (DO_STEP && p.noise != nullptr)
       for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
     if constexpr (sizeof(T) == 4) {
-      if (small_threads(p.B, 4) == kSmallThreadsBig) {
-        if (sv == SMALL_TAG_3_1_2)
-          return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, kSmallThreadsBig, DO_STEP, DO_OBS>(p, noise, s);
-        return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, kSmallThreadsBig, DO_STEP, DO_OBS>(p, noise, s);
-      }
+      if (threads == kSmallThreadsBig) return launch_small_id<T, kSmallThreadsBig, DO_STEP, DO_OBS>(sv, p, noise, s);
     }
-    if (sv == SMALL_TAG_3_1_2)
-      return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, kSmallThreads, DO_STEP, DO_OBS>(p, noise, s);
-    return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, kSmallThreads, DO_STEP, DO_OBS>(p, noise, s);
+    return launch_small_id<T, kSmallThreads, DO_STEP, DO_OBS>(sv, p, noise, s);
   }
   // Large worlds are LDS-limited to 1-2 workgroups per CU: give those workgroups more wavefronts so
   // the compute-heavy pair phase and the store-heavy observation phase still find work to overlap.
@@ -216,7 +273,8 @@ extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dty
   if (rc) return rc;
   if (B < 1) return MPE_ERR_BATCH;
   if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
-  if (!g_force_tile && small_variant(h) != SMALL_NONE) return (B + small_threads(B, dtype_bytes) - 1) / small_threads(B, dtype_bytes);
+  const int threads = small_launch_threads(h, B, dtype_bytes, nullptr);
+  if (threads != 0) return (B + threads - 1) / threads;
   return tile_grid(B, dtype_bytes == 4 ? 64 : 32);
 }
 
@@ -247,16 +305,19 @@ static int world_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, co
 }
 
 template <typename T>
-static int observe_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const T *pos, const T *vel, T *obs,
-                        T *rew, T *info, void *stream) {
+static int observe_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const T *pos, const T *vel,
+                        const int32_t *goal, T *obs, T *rew, T *info, void *stream) {
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
   if (!pos || !vel) return MPE_ERR_NULL;
+  if (info_width_of(h) == 0) info = nullptr;  // scenario has no benchmark_data
   if (!obs && !rew && !info) return MPE_ERR_NULL;
-  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(obs) || misaligned<T>(rew) || misaligned<T>(info))
+  if (kind_has_goal(h->kind) && !goal) return MPE_ERR_NULL;
+  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(obs) || misaligned<T>(rew) ||
+      misaligned<T>(info) || misaligned<int32_t>(goal))
     return MPE_ERR_ALIGN;
   KParams<T> p{};
-  p.pos = const_cast<T *>(pos); p.vel = const_cast<T *>(vel);
+  p.pos = const_cast<T *>(pos); p.vel = const_cast<T *>(vel); p.goal = goal;
   p.obs = obs; p.rew = rew; p.info = info;
   p.B = B; p.ld = ld;
   to_device_desc<T>(h, p.d);
@@ -265,16 +326,19 @@ static int observe_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
 
 template <typename T>
 static int env_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const T *act, const T *noise, T *pos,
-                         T *vel, T *comm, T *obs, T *rew, T *info, double *stats, void *stream) {
+                         T *vel, T *comm, const int32_t *goal, T *obs, T *rew, T *info, double *stats,
+                         void *stream) {
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
   if (!act || !pos || !vel) return MPE_ERR_NULL;
+  if (kind_has_goal(h->kind) && !goal) return MPE_ERR_NULL;
+  if (info_width_of(h) == 0) info = nullptr;  // scenario has no benchmark_data
   if (misaligned<T>(act) || misaligned<T>(noise) || misaligned<T>(pos) || misaligned<T>(vel) ||
       misaligned<T>(comm) || misaligned<T>(obs) || misaligned<T>(rew) || misaligned<T>(info) ||
-      misaligned<double>(stats))
+      misaligned<double>(stats) || misaligned<int32_t>(goal))
     return MPE_ERR_ALIGN;
   KParams<T> p{};
-  p.act = act; p.noise = noise; p.pos = pos; p.vel = vel; p.comm = comm;
+  p.act = act; p.noise = noise; p.pos = pos; p.vel = vel; p.comm = comm; p.goal = goal;
   p.obs = obs; p.rew = rew; p.info = info; p.stats = stats;
   p.B = B; p.ld = ld;
   to_device_desc<T>(h, p.d);
@@ -288,11 +352,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E, int A, int dim_c, double ra,
                                                      double rl, uint32_t k0, uint32_t k1, uint32_t episode,
                                                      uint64_t env_id0, const uint8_t *mask, T *pos, T *vel,
-                                                     T *comm) {
+                                                     T *comm, int32_t *goal) {
   const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (env >= B) return;
   if (mask != nullptr && mask[env] == 0) return;
   const uint64_t gid = env_id0 + (uint64_t)env;
+  if (goal != nullptr) {  // goal = np.random.choice(world.landmarks) (simple_adversary.py:45)
+    uint32_t w[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), episode, 0xFFFFFFFFu, k0, k1, w);
+    goal[env] = (int32_t)(((uint64_t)w[0] * (uint64_t)(E - A)) >> 32);
+  }
   for (int e = 0; e < E; ++e) {
     uint32_t w[4];
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), episode, (uint32_t)e, k0, k1, w);
@@ -307,16 +376,19 @@ __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E
 
 template <typename T>
 static int reset_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_t seed, uint32_t episode,
-                      uint64_t env_id0, const uint8_t *mask, T *pos, T *vel, T *comm, void *stream) {
+                      uint64_t env_id0, const uint8_t *mask, T *pos, T *vel, T *comm, int32_t *goal,
+                      void *stream) {
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
   if (!pos || !vel) return MPE_ERR_NULL;
-  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm)) return MPE_ERR_ALIGN;
+  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm) || misaligned<int32_t>(goal))
+    return MPE_ERR_ALIGN;
+  if (h->n_landmarks < 1) goal = nullptr;
   const dim3 grid((unsigned)((B + 255) / 256)), block(256);
   hipLaunchKernelGGL(reset_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld,
                      h->n_agents + h->n_landmarks, h->n_agents, h->dim_c, h->agent_pos_range,
                      h->landmark_pos_range, (uint32_t)seed, (uint32_t)(seed >> 32), episode, env_id0, mask, pos,
-                     vel, comm);
+                     vel, comm, goal);
   return (int)hipGetLastError();
 }
 
@@ -353,18 +425,19 @@ extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, do
     return world_step_impl<T>(d, B, ld, act, noise, pos, vel, comm, stream);                                   \
   }                                                                                                            \
   extern "C" int mpe_observe_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const T *pos,            \
-                                   const T *vel, T *obs, T *rew, T *info, void *stream) {                      \
-    return observe_impl<T>(d, B, ld, pos, vel, obs, rew, info, stream);                                        \
+                                   const T *vel, const int32_t *goal, T *obs, T *rew, T *info,                 \
+                                   void *stream) {                                                             \
+    return observe_impl<T>(d, B, ld, pos, vel, goal, obs, rew, info, stream);                                  \
   }                                                                                                            \
   extern "C" int mpe_env_step_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const T *act,           \
-                                    const T *noise, T *pos, T *vel, T *comm, T *obs, T *rew, T *info,          \
-                                    double *stats, void *stream) {                                             \
-    return env_step_impl<T>(d, B, ld, act, noise, pos, vel, comm, obs, rew, info, stats, stream);              \
+                                    const T *noise, T *pos, T *vel, T *comm, const int32_t *goal, T *obs,      \
+                                    T *rew, T *info, double *stats, void *stream) {                            \
+    return env_step_impl<T>(d, B, ld, act, noise, pos, vel, comm, goal, obs, rew, info, stats, stream);        \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
                                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, T *pos, T *vel,      \
-                                 T *comm, void *stream) {                                                      \
-    return reset_impl<T>(d, B, ld, seed, episode, env_id0, mask, pos, vel, comm, stream);                      \
+                                 T *comm, int32_t *goal, void *stream) {                                       \
+    return reset_impl<T>(d, B, ld, seed, episode, env_id0, mask, pos, vel, comm, goal, stream);                \
   }
 
 MPE_EXPORT_TYPED(f32, float)

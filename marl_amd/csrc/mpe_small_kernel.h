@@ -38,7 +38,11 @@ template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool HAS_NO
 __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr bool TAG = KIND == MPE_SIMPLE_TAG;
-  constexpr int ECOL = TAG ? E : A;  // entities that collide (stock flags)
+  constexpr bool F1 = KIND >= MPE_SIMPLE;  // simple / simple_adversary / simple_push gathers
+  constexpr bool HAS_GOAL = KIND == MPE_SIMPLE_ADVERSARY || KIND == MPE_SIMPLE_PUSH;
+  // entities that collide (stock flags): everything in simple_tag, the agents in simple_spread and
+  // simple_push, nothing in simple and simple_adversary
+  constexpr int ECOL = TAG ? E : ((KIND == MPE_SIMPLE_SPREAD || KIND == MPE_SIMPLE_PUSH) ? A : 0);
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
   const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
@@ -110,7 +114,118 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
       for (int r = 0; r < A * d.dim_c; ++r) (p.comm + blk0 + (int64_t)r * ld)[lo] = T(0);
   }
 
-  if (DO_OBS) {
+  if constexpr (DO_OBS && F1) {
+    // ---- simple.py:41-50 / simple_adversary.py:58-140 / simple_push.py:66-104 ------------------------
+    int goal = 0;
+    T gx = px[A], gy = py[A];
+    if (HAS_GOAL) {  // agent.goal_a: per-env landmark index
+      goal = p.goal[blk0 + lo];
+      goal = goal < 0 ? 0 : (goal >= L ? L - 1 : goal);
+#pragma unroll
+      for (int l = 1; l < L; ++l) {
+        gx = goal == l ? px[A + l] : gx;
+        gy = goal == l ? py[A + l] : gy;
+      }
+    }
+    if (p.obs != nullptr && active) {
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+        T *o = p.obs + blk0 + (int64_t)d.obs_row0[i] * ld;
+        int r = 0;
+        if (KIND != MPE_SIMPLE_ADVERSARY) {
+          st_stream(o + (int64_t)(r++) * ld + lo, vx[i]);
+          st_stream(o + (int64_t)(r++) * ld + lo, vy[i]);
+        }
+        if (HAS_GOAL && i >= NADV) {
+          st_stream(o + (int64_t)(r++) * ld + lo, gx - px[i]);
+          st_stream(o + (int64_t)(r++) * ld + lo, gy - py[i]);
+          if (KIND == MPE_SIMPLE_PUSH) {  // agent.color (simple_push.py:51-56)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              st_stream(o + (int64_t)(r++) * ld + lo, k == goal + 1 ? T(0.25) + T(0.5) : T(0.25));
+          }
+        }
+#pragma unroll
+        for (int l = A; l < E; ++l) {
+          st_stream(o + (int64_t)(r++) * ld + lo, px[l] - px[i]);
+          st_stream(o + (int64_t)(r++) * ld + lo, py[l] - py[i]);
+        }
+        if (KIND == MPE_SIMPLE_PUSH && i >= NADV) {  // landmark.color (simple_push.py:43-45)
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              st_stream(o + (int64_t)(r++) * ld + lo, k == l + 1 ? T(0.1) + T(0.8) : T(0.1));
+        }
+        if (KIND != MPE_SIMPLE) {
+#pragma unroll
+          for (int j = 0; j < A; ++j) {
+            if (j == i) continue;
+            st_stream(o + (int64_t)(r++) * ld + lo, px[j] - px[i]);
+            st_stream(o + (int64_t)(r++) * ld + lo, py[j] - py[i]);
+          }
+        }
+      }
+    }
+    const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;
+    if (want_rew || want_info || want_stats) {
+      T m = T(0), adv_rew = T(0);
+      if (HAS_GOAL) {
+#pragma unroll
+        for (int g = NADV; g < A; ++g) {
+          const T dist = t_sqrt<T>(sqdist<T>(px[g], py[g], gx, gy));
+          m = (g == NADV || dist < m) ? dist : m;
+        }
+        if (KIND == MPE_SIMPLE_ADVERSARY) {
+#pragma unroll
+          for (int a = 0; a < NADV; ++a) adv_rew = adv_rew + t_sqrt<T>(sqdist<T>(px[a], py[a], gx, gy));
+        }
+      }
+      T rew[A];
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+        if (KIND == MPE_SIMPLE) {
+          rew[i] = -sqdist<T>(px[i], py[i], px[A], py[A]);
+        } else if (KIND == MPE_SIMPLE_ADVERSARY) {
+          rew[i] = i < NADV ? -sqdist<T>(px[i], py[i], gx, gy) : -m + adv_rew;
+        } else {
+          const T dg = t_sqrt<T>(sqdist<T>(px[i], py[i], gx, gy));
+          rew[i] = i < NADV ? m - dg : -dg;
+        }
+        if (want_rew && active) st_stream(p.rew + blk0 + (int64_t)i * ld + lo, rew[i]);
+        if (KIND == MPE_SIMPLE_ADVERSARY && want_info && active) {  // simple_adversary.py:58-67
+          T *ir = p.info + blk0 + (int64_t)((L + 1) * i) * ld + lo;
+          const T dgoal = sqdist<T>(px[i], py[i], gx, gy);
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+            st_stream(ir + (int64_t)l * ld,
+                      i < NADV ? (l == 0 ? dgoal : T(0)) : sqdist<T>(px[i], py[i], px[A + l], py[A + l]));
+          st_stream(ir + (int64_t)L * ld, i < NADV ? T(0) : dgoal);
+        }
+      }
+      if (want_stats) {
+        constexpr int W = 2 * A + 2;
+        constexpr int NW = THREADS / 64;
+        __shared__ double sred1[NW][A + 1];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+          const double s_r = group_sum(active ? (double)rew[i] : 0.0, 64);
+          if (lane == 0) sred1[wave][i] = s_r;
+        }
+        if (lane == 0) sred1[wave][A] = (double)__builtin_popcountll(__ballot(active));
+        __syncthreads();
+        if (threadIdx.x <= A) {
+          double s = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += sred1[w][threadIdx.x];
+          p.stats[(int64_t)blockIdx.x * W + (threadIdx.x < A ? threadIdx.x : 2 * A + 1)] += s;
+        }
+      }
+    }
+  }
+
+  if constexpr (DO_OBS && !F1) {
     // ---- observations (simple_tag.py:131-147 / simple_spread.py:83-99) ---------------------------
     if (p.obs != nullptr && active) {
 #pragma unroll

@@ -139,6 +139,16 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
       const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr,
                  want_stats = p.stats != nullptr;
       double *srow = want_stats ? p.stats + (int64_t)blockIdx.x * (2 * A + 2) : nullptr;
+      // goal landmark of this env (agent.goal_a), scenarios with a goal only
+      const bool has_goal = kind_has_goal(d.kind);
+      int goal = 0;
+      T gx = T(0), gy = T(0);
+      if (has_goal) {
+        goal = p.goal[ge];
+        goal = goal < 0 ? 0 : (goal >= L ? L - 1 : goal);
+        gx = sPos[(2 * (A + goal)) * TILE + lane];
+        gy = sPos[(2 * (A + goal) + 1) * TILE + lane];
+      }
       // ---- phase 3a: observations (simple_tag.py:131-147 / simple_spread.py:83-99) -----------------
 #ifdef MPE_ABL_NO_OBS
       if (p.obs != nullptr && active && p.B < 0) {
@@ -148,21 +158,45 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
-          st_stream(o, sVel[(2 * i) * TILE + lane]);
-          st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
-          st_stream(o + 2 * ld, pix);
-          st_stream(o + 3 * ld, piy);
-          o += 4 * ld;
+          if (d.kind == MPE_SIMPLE_TAG || d.kind == MPE_SIMPLE_SPREAD) {
+            st_stream(o, sVel[(2 * i) * TILE + lane]);
+            st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+            st_stream(o + 2 * ld, pix);
+            st_stream(o + 3 * ld, piy);
+            o += 4 * ld;
+          } else {
+            // simple.py:45-50 / simple_adversary.py:122-140 / simple_push.py:84-104
+            const bool i_good = !bit(d.adversary, i);
+            if (d.kind != MPE_SIMPLE_ADVERSARY) {
+              st_stream(o, sVel[(2 * i) * TILE + lane]);
+              st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+              o += 2 * ld;
+            }
+            if (has_goal && i_good) {
+              st_stream(o, gx - pix);
+              st_stream(o + ld, gy - piy);
+              o += 2 * ld;
+              if (d.kind == MPE_SIMPLE_PUSH) {  // agent.color (simple_push.py:51-56)
+                for (int k = 0; k < 3; ++k) { st_stream(o, k == goal + 1 ? T(0.25) + T(0.5) : T(0.25)); o += ld; }
+              }
+            }
+          }
           for (int l = A; l < E; ++l) {
             st_stream(o, sPos[(2 * l) * TILE + lane] - pix);
             st_stream(o + ld, sPos[(2 * l + 1) * TILE + lane] - piy);
             o += 2 * ld;
           }
-          for (int j = 0; j < A; ++j) {
-            if (j == i) continue;
-            st_stream(o, sPos[(2 * j) * TILE + lane] - pix);
-            st_stream(o + ld, sPos[(2 * j + 1) * TILE + lane] - piy);
-            o += 2 * ld;
+          if (d.kind == MPE_SIMPLE_PUSH && !bit(d.adversary, i)) {  // landmark.color (simple_push.py:43-45)
+            for (int l = 0; l < L; ++l)
+              for (int k = 0; k < 3; ++k) { st_stream(o, k == l + 1 ? T(0.1) + T(0.8) : T(0.1)); o += ld; }
+          }
+          if (d.kind != MPE_SIMPLE) {
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              st_stream(o, sPos[(2 * j) * TILE + lane] - pix);
+              st_stream(o + ld, sPos[(2 * j + 1) * TILE + lane] - piy);
+              o += 2 * ld;
+            }
           }
           if (d.kind == MPE_SIMPLE_TAG) {
             for (int j = 0; j < A; ++j) {
@@ -171,7 +205,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               st_stream(o + ld, sVel[(2 * j + 1) * TILE + lane]);
               o += 2 * ld;
             }
-          } else {
+          } else if (d.kind == MPE_SIMPLE_SPREAD) {
             for (int z = 0; z < d.dim_c * (A - 1); ++z) { st_stream(o, T(0)); o += ld; }
           }
         }
@@ -239,6 +273,53 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_t = group_sum(active ? (double)total : 0.0, TILE);
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        } else if (d.kind != MPE_SIMPLE_SPREAD) {
+          // simple.py:41-43 / simple_adversary.py:58-119 / simple_push.py:66-82.  The per-env scalars
+          // (nearest good agent to the goal, summed adversary distances) are recomputed by every
+          // chunk: these worlds are small.
+          T m = T(0), adv_rew = T(0);
+          if (has_goal) {
+            for (int gi = 0; gi < d.n_good; ++gi) {
+              const int g = d.good_list[gi];
+              const T dist = t_sqrt<T>(sqdist<T>(sPos[(2 * g) * TILE + lane], sPos[(2 * g + 1) * TILE + lane], gx, gy));
+              m = (gi == 0 || dist < m) ? dist : m;
+            }
+            if (d.kind == MPE_SIMPLE_ADVERSARY)
+              for (int ai = 0; ai < d.n_adv; ++ai) {
+                const int a = d.adv_list[ai];
+                adv_rew = adv_rew + t_sqrt<T>(sqdist<T>(sPos[(2 * a) * TILE + lane], sPos[(2 * a + 1) * TILE + lane], gx, gy));
+              }
+          }
+          for (int i = chunk; i < A; i += NCH) {
+            const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+            const bool i_adv = bit(d.adversary, i);
+            T r_i;
+            if (d.kind == MPE_SIMPLE) {
+              r_i = -sqdist<T>(pix, piy, sPos[(2 * A) * TILE + lane], sPos[(2 * A + 1) * TILE + lane]);
+            } else if (d.kind == MPE_SIMPLE_ADVERSARY) {
+              r_i = i_adv ? -sqdist<T>(pix, piy, gx, gy) : -m + adv_rew;
+            } else {
+              const T dg = t_sqrt<T>(sqdist<T>(pix, piy, gx, gy));
+              r_i = i_adv ? m - dg : -dg;
+            }
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_info && active && d.info_w > 0) {  // simple_adversary.py:58-67
+              T *ir = p.info + (int64_t)(d.info_w * i) * ld + env;
+              for (int l = 0; l < L; ++l) {
+                const T v = sqdist<T>(pix, piy, sPos[(2 * (A + l)) * TILE + lane], sPos[(2 * (A + l) + 1) * TILE + lane]);
+                st_stream(ir + (int64_t)l * ld, i_adv ? (l == 0 ? sqdist<T>(pix, piy, gx, gy) : T(0)) : v);
+              }
+              st_stream(ir + (int64_t)L * ld, i_adv ? T(0) : sqdist<T>(pix, piy, gx, gy));
+            }
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              if (lane == 0) srow[i] += s_r;
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) srow[2 * A + 1] += s_n;
           }
         } else {
           // simple_spread: m_l = min_a dist(a, landmark l) (simple_spread.py:74-76), summed in

@@ -107,7 +107,7 @@ class MultiAgentEnv(object):
             obs_n = list(world.obs_views)
             reward_n = [world.rew[i] for i in range(self.n)]
             if self.info_callback is not None:
-                info_n = {'n': [self._scenario._format_info(world.info[i]) for i in range(self.n)]}
+                info_n = {'n': [self._scenario._format_info(world.info[i], self.agents[i]) for i in range(self.n)]}
             else:
                 info_n = {'n': list(self._empty_info)}
         else:

@@ -40,6 +40,7 @@ class HipScenario(BaseScenario):
         _hip.check(fn(d, world.num_envs, world.num_envs, world.seed, world.episode, world.env_id0,
                       _hip.ptr(mask), world.pos.data_ptr(), world.vel.data_ptr(),
                       world.comm.data_ptr() if world.comm.numel() else None,
+                      world.goal.data_ptr() if world.hip_kind in _hip.GOAL_KINDS else None,
                       _hip.stream_of(world.device)), 'mpe_reset')
         world.episode += 1
         world.mark_dirty()
@@ -54,7 +55,7 @@ class HipScenario(BaseScenario):
 
     def benchmark_data(self, agent, world):
         world.gather()
-        return self._format_info(world.info[agent._index])
+        return self._format_info(world.info[agent._index], agent)
 
-    def _format_info(self, rows):
+    def _format_info(self, rows, agent):
         raise NotImplementedError()

@@ -1,16 +1,17 @@
-"""Cooperative navigation (reference: build/lib/multiagent/scenarios/simple_spread.py).
-
-``benchmark_data`` returns the reference's 4-tuple (rew, collisions, min_dists,
-occupied_landmarks) (simple_spread.py:46-62), each element a ``[B]`` tensor."""
+"""Keep-away (reference: build/lib/multiagent/scenarios/simple_push.py; this fork's copy has 10
+agents -- 9 adversaries first -- and 1 landmark).  The good agent's observation carries its colour
+and the landmark colours (simple_push.py:43-56,101).  No benchmark_data in the reference."""
 from marl_amd import _hip
 from marl_amd.core import World, Agent, Landmark
 from marl_amd.scenario import HipScenario
 
 
 class Scenario(HipScenario):
-    def __init__(self, num_envs=1, device=None, dtype=None, seed=0, num_agents=3, num_landmarks=3):
+    def __init__(self, num_envs=1, device=None, dtype=None, seed=0, num_agents=10, num_adversaries=9,
+                 num_landmarks=1):
         super(Scenario, self).__init__(num_envs, device, dtype, seed)
         self.num_agents = num_agents
+        self.num_adversaries = num_adversaries
         self.num_landmarks = num_landmarks
 
     def make_world(self):
@@ -21,16 +22,17 @@ class Scenario(HipScenario):
             agent.name = 'agent %d' % i
             agent.collide = True
             agent.silent = True
-            agent.size = 0.15
+            agent.adversary = i < self.num_adversaries
         world.landmarks = [Landmark() for _ in range(self.num_landmarks)]
         for i, landmark in enumerate(world.landmarks):
             landmark.name = 'landmark %d' % i
             landmark.collide = False
             landmark.movable = False
-        world.hip_kind = _hip.MPE_SIMPLE_SPREAD
-        world.agent_pos_range = 1.0        # simple_spread.py:39
-        world.landmark_pos_range = 1.0     # simple_spread.py:43
+        world.hip_kind = _hip.MPE_SIMPLE_PUSH
+        world.agent_pos_range = 1.0        # simple_push.py:59
+        world.landmark_pos_range = 1.0     # simple_push.py:63
         return self._finish_world(world)
 
-    def _format_info(self, rows, agent):
-        return (rows[0], rows[1], rows[2], rows[3])
+    @property
+    def benchmark_data(self):
+        raise AttributeError("'Scenario' object has no attribute 'benchmark_data' (simple_push.py defines none)")

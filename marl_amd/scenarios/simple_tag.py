@@ -46,5 +46,5 @@ class Scenario(HipScenario):
     def adversaries(self, world):
         return [agent for agent in world.agents if agent.adversary]
 
-    def _format_info(self, rows):
+    def _format_info(self, rows, agent):
         return rows[0]

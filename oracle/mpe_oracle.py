@@ -629,6 +629,20 @@ def _u01(hi, lo):
     return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0)
 
 
+def reset_goals(spec: ScenarioSpec, seed: int, episode, env_ids):
+    """Goal landmark index per env: Philox word 0 at entity = 0xFFFFFFFF, mapped to [0, L) by
+    (w * L) >> 32  (the reference: np.random.choice(world.landmarks), simple_adversary.py:45)."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    B = env_ids.shape[0]
+    episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), (B,))
+    lo = (env_ids & _MASK).astype(np.uint32)
+    hi = (env_ids >> np.uint64(32)).astype(np.uint32)
+    k0 = np.full(B, seed & 0xFFFFFFFF, np.uint32)
+    k1 = np.full(B, (seed >> 32) & 0xFFFFFFFF, np.uint32)
+    w = philox4x32_10([lo, hi, episode, np.full(B, 0xFFFFFFFF, np.uint32)], [k0, k1])
+    return ((w[0].astype(np.uint64) * np.uint64(spec.n_landmarks)) >> np.uint64(32)).astype(np.int32)
+
+
 def reset_positions(spec: ScenarioSpec, seed: int, episode, env_ids, dtype=np.float64):
     """pos[E,2,B] for envs ``env_ids`` (global ids) at per-env episode counter ``episode``.
 

@@ -31,11 +31,14 @@ class HipSim:
         self.obs = torch.full((sum(spec.obs_dims), self.ld), float('nan'), **z)
         self.rew = torch.full((A, self.ld), float('nan'), **z)
         self.info = torch.full((A, spec.info_width, self.ld), float('nan'), **z)
+        self.goal = torch.zeros(self.ld, dtype=torch.int32, device='cuda')
         self.stream = torch.cuda.current_stream().cuda_stream
 
-    def set_state(self, pos, vel):
+    def set_state(self, pos, vel, goal=None):
         self.pos[:, :, :self.B] = dev(pos, self.dtype)
         self.vel[:, :, :self.B] = dev(vel, self.dtype)
+        if goal is not None:
+            self.goal[:self.B] = torch.as_tensor(np.maximum(np.asarray(goal), 0), dtype=torch.int32).cuda()
 
     def _p(self, t):
         return None if t is None else t.data_ptr()
@@ -44,8 +47,8 @@ class HipSim:
         self._act, self._noise = act, noise   # keep alive until the stream has consumed them
         rc = getattr(lib, 'mpe_env_step_' + self.suf)(
             self.desc, self.B, self.ld, act.data_ptr(), self._p(noise), self.pos.data_ptr(), self.vel.data_ptr(),
-            None, self.obs.data_ptr(), self.rew.data_ptr(), self.info.data_ptr() if want_info else None,
-            self._p(stats), self.stream)
+            None, self.goal.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
+            self.info.data_ptr() if (want_info and self.info.numel()) else None, self._p(stats), self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def world_step(self, act, noise=None, comm=None):
@@ -57,15 +60,15 @@ class HipSim:
 
     def observe(self, obs=True, rew=True, info=True):
         rc = getattr(lib, 'mpe_observe_' + self.suf)(
-            self.desc, self.B, self.ld, self.pos.data_ptr(), self.vel.data_ptr(),
+            self.desc, self.B, self.ld, self.pos.data_ptr(), self.vel.data_ptr(), self.goal.data_ptr(),
             self.obs.data_ptr() if obs else None, self.rew.data_ptr() if rew else None,
-            self.info.data_ptr() if info else None, self.stream)
+            self.info.data_ptr() if (info and self.info.numel()) else None, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def reset(self, seed, episode, env_id0=0, mask=None):
         rc = getattr(lib, 'mpe_reset_' + self.suf)(
             self.desc, self.B, self.ld, seed, episode, env_id0, self._p(mask), self.pos.data_ptr(),
-            self.vel.data_ptr(), None, self.stream)
+            self.vel.data_ptr(), None, self.goal.data_ptr(), self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def host(self):

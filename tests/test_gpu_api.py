@@ -178,3 +178,49 @@ def test_episode_stats_all_reduce_single_process():
     assert s['env_steps'] == 25 * 2048 and s['episodes'] == 2048
     np.testing.assert_allclose(s['mean_episode_reward'], (tot_r / 2048).cpu().numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(s['collisions_per_episode'], (tot_c / 2048).cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize('name,spec', [('simple', O.simple_spec()), ('simple_adversary', O.simple_adversary_spec()),
+                                       ('simple_push', O.simple_push_spec())])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+def test_f1_scenarios_episode_loop_matches_oracle(name, spec, dtype, tol):
+    """SURVEY 8f row f1 through the public API: reset (Philox positions + goal) and 25 steps."""
+    from marl_amd import make_env
+    B, T = 384, 25
+    env = make_env(name, benchmark=(name == 'simple_adversary'), num_envs=B, dtype=dtype, seed=5)
+    assert [s.shape[0] for s in env.observation_space] == spec.obs_dims
+    obs_n = env.reset()
+    w = env.world
+    ids = np.arange(B, dtype=np.uint64)
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    assert np.array_equal(w.pos.cpu().numpy(), O.reset_positions(spec, 5, w.episode - 1, ids, npdt))
+    goal = w.goal.cpu().numpy()
+    if spec.kind in O.GOAL_KINDS:
+        assert np.array_equal(goal, O.reset_goals(spec, 5, w.episode - 1, ids))
+    bo = O.BatchedOracle(spec)
+    pos, vel = _np(w.pos), _np(w.vel)
+    obs0, _, _ = bo.observe(pos, vel, goal=goal)
+    for i in range(env.n):
+        np.testing.assert_allclose(_np(obs_n[i]).T, obs0[i], rtol=0, atol=tol)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for t in range(T):
+        action_n = [torch.softmax(torch.randn(B, 5, generator=gen, device='cuda', dtype=dtype), -1) for _ in range(env.n)]
+        if dtype == torch.float32:
+            pos, vel = _np(w.pos), _np(w.vel)
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, np.stack([_np(a).T for a in action_n]), goal=goal)
+        np.testing.assert_allclose(_np(w.pos), pos, rtol=tol, atol=tol)
+        np.testing.assert_allclose(_np(w.vel), vel, rtol=tol, atol=tol)
+        for i in range(env.n):
+            np.testing.assert_allclose(_np(new_obs_n[i]).T, obs[i], rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.stack([_np(x) for x in rew_n]), rew, rtol=tol, atol=tol * 10)
+        if name == 'simple_adversary':
+            assert tuple(info_n['n'][0].shape) == (B,)                        # adversary: scalar per env
+            np.testing.assert_allclose(_np(info_n['n'][0]), info[0, 0], rtol=tol, atol=tol)
+            got = np.stack([_np(c) for c in info_n['n'][1]])                  # good agent: L+1 tuple
+            np.testing.assert_allclose(got, info[1], rtol=tol, atol=tol)
+        else:
+            assert info_n == {'n': [{}] * env.n}
+    if name != 'simple_adversary':
+        with pytest.raises(AttributeError):                                   # like the reference
+            make_env(name, benchmark=True, num_envs=4)

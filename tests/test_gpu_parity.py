@@ -31,6 +31,11 @@ CASES = [
     ('g5_simple_tag_dense', lambda: O.simple_tag_spec()),
     ('g5_simple_spread_dense', lambda: O.simple_spread_spec()),
     ('g6_simple_tag_oob', lambda: O.simple_tag_spec()),
+    ('g7_simple', lambda: O.simple_spec()),
+    ('g8_simple_adversary', lambda: O.simple_adversary_spec()),
+    ('g8_simple_adversary_dense', lambda: O.simple_adversary_spec()),
+    ('g9_simple_push', lambda: O.simple_push_spec()),
+    ('g9_simple_push_dense', lambda: O.simple_push_spec()),
 ]
 
 
@@ -56,7 +61,7 @@ def test_f64_trajectory_matches_reference(golden_dir, name, mk, force_tile):
     spec = mk()
     S, T = g['act'].shape[:2]
     sim = HipSim(spec, S, torch.float64)
-    sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'))
+    sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'), g['goal'])
     sim.observe(rew=False, info=False)
     assert _maxerr(sim.host()[2], g['obs0'].T) == 0.0          # pure gathers/subtractions: exact
     worst = 0.0
@@ -86,7 +91,7 @@ def test_f32_teacher_forced_matches_reference(golden_dir, name, mk, force_tile):
     for t in range(T):
         p0 = golden_soa(g, 'pos0') if t == 0 else golden_soa(g, 'pos', t - 1)
         v0 = golden_soa(g, 'vel0') if t == 0 else golden_soa(g, 'vel', t - 1)
-        sim.set_state(p0, v0)
+        sim.set_state(p0, v0, g['goal'])
         act = dev(golden_soa(g, 'act', t), torch.float32)
         noise = dev(golden_soa(g, 'noise', t), torch.float32) if 'noise' in g.files else None
         sim.env_step(act, noise)
@@ -102,9 +107,11 @@ def test_f32_teacher_forced_matches_reference(golden_dir, name, mk, force_tile):
         if spec.kind == O.SIMPLE_TAG:
             ax = np.abs(P[:A])
             near |= (np.abs(ax - 0.9) < 1e-5).any((0, 1)) | (np.abs(ax - 1.0) < 1e-5).any((0, 1))
-        else:
+        elif spec.kind == O.SIMPLE_SPREAD:
             dl = np.sqrt(((P[:A, None] - P[None, A:]) ** 2).sum(2))
             near |= (np.abs(dl - 0.1) < 1e-5).any((0, 1))
+        else:
+            near[:] = False                      # no thresholds in simple / simple_adversary / simple_push
         ok = ~near
         np.testing.assert_allclose(rew[:, ok], golden_soa(g, 'rew', t)[:, ok], rtol=1e-4, atol=2e-4)
         np.testing.assert_allclose(info[..., ok], golden_soa(g, 'info', t)[..., ok], rtol=1e-4, atol=2e-4)
@@ -113,8 +120,12 @@ def test_f32_teacher_forced_matches_reference(golden_dir, name, mk, force_tile):
 
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
 @pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec(),
-                                lambda: O.simple_tag_spec(5, 3, 4), lambda: O.simple_spread_spec(5, 7)],
-                         ids=['tag', 'spread', 'tag_5_3_4', 'spread_5_7'])
+                                lambda: O.simple_tag_spec(5, 3, 4), lambda: O.simple_spread_spec(5, 7),
+                                lambda: O.simple_spec(), lambda: O.simple_adversary_spec(),
+                                lambda: O.simple_adversary_spec(6), lambda: O.simple_push_spec(),
+                                lambda: O.simple_push_spec(5, 3, 2)],
+                         ids=['tag', 'spread', 'tag_5_3_4', 'spread_5_7', 'simple', 'adversary', 'adversary_6',
+                              'push', 'push_5_3_2'])
 def test_split_entry_points_equal_fused(mk, dtype, force_tile):
     """mpe_world_step + mpe_observe == mpe_env_step, bit for bit; ragged batch (B not a tile multiple)
     inside a larger allocation (ld > B): rows beyond B must stay untouched."""
@@ -126,8 +137,9 @@ def test_split_entry_points_equal_fused(mk, dtype, force_tile):
     act = torch.zeros(spec.n_agents, 5, ld, dtype=dtype, device='cuda')
     act[:, :, :B] = dev(rng.rand(spec.n_agents, 5, B), dtype)
     a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
-    a.set_state(pos, vel)
-    b.set_state(pos, vel)
+    goal = rng.randint(0, max(spec.n_landmarks, 1), B)
+    a.set_state(pos, vel, goal)
+    b.set_state(pos, vel, goal)
     comm = torch.full((spec.n_agents, spec.dim_c, ld), 7.0, dtype=dtype, device='cuda')
     for _ in range(3):
         a.env_step(act)
@@ -141,7 +153,9 @@ def test_split_entry_points_equal_fused(mk, dtype, force_tile):
     assert (a.pos[..., B:] == 0).all() and (a.vel[..., B:] == 0).all()
 
 
-@pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec()], ids=['tag', 'spread'])
+@pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec(), lambda: O.simple_spec(),
+                                lambda: O.simple_adversary_spec(), lambda: O.simple_push_spec()],
+                         ids=['tag', 'spread', 'simple', 'adversary', 'push'])
 def test_small_and_tile_kernels_bit_identical(mk):
     """The register kernel and the LDS-tile kernel implement the same operation order."""
     spec = mk()
@@ -155,7 +169,7 @@ def test_small_and_tile_kernels_bit_identical(mk):
         for ft in (0, 1):
             lib.mpe_debug_force_tile_kernel(ft)
             sim = HipSim(spec, B, dtype)
-            sim.set_state(pos, vel)
+            sim.set_state(pos, vel, np.arange(B) % max(spec.n_landmarks, 1))
             for _ in range(5):
                 sim.env_step(act)
             res.append(sim.host())
@@ -287,6 +301,13 @@ def test_reset_matches_philox_oracle(dtype, force_tile):
     want = O.reset_positions(spec, 1, 0, np.arange(16, dtype=np.uint64) + np.uint64((1 << 40) + 5),
                              np.float64 if dtype == torch.float64 else np.float32)
     assert np.array_equal(big.pos.cpu().numpy(), want)
+    # goal landmark draw (simple_adversary / simple_push): same stream, entity word 0xFFFFFFFF
+    adv = O.simple_adversary_spec(5)
+    ga = HipSim(adv, 3000, dtype)
+    ga.reset(seed=99, episode=2, env_id0=17)
+    want_goal = O.reset_goals(adv, 99, 2, np.arange(3000, dtype=np.uint64) + np.uint64(17))
+    assert np.array_equal(ga.goal.cpu().numpy(), want_goal)
+    assert set(np.unique(want_goal)) == {0, 1, 2, 3}
     # mask
     before = sim.pos.clone()
     mask = (torch.arange(B, device='cuda') % 3 == 0).to(torch.uint8)
@@ -351,7 +372,7 @@ def test_c_abi_rejects_bad_arguments():
     sim = HipSim(spec, 8, torch.float64)
     act = torch.zeros(4, 5, 8, dtype=torch.float64, device='cuda')
     f = lib.mpe_env_step_f64
-    args = [sim.desc, 8, 8, act.data_ptr(), None, sim.pos.data_ptr(), sim.vel.data_ptr(), None,
+    args = [sim.desc, 8, 8, act.data_ptr(), None, sim.pos.data_ptr(), sim.vel.data_ptr(), None, None,
             sim.obs.data_ptr(), sim.rew.data_ptr(), sim.info.data_ptr(), None, sim.stream]
     assert f(*args) == 0
     bad = list(args); bad[1] = 0

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_hip._LIB_PATH)
     for n in names:
         assert hasattr(raw, n), 'libmpe_hip.so does not export %s' % n
-    assert _hip.lib.mpe_abi_version() == 1
+    assert _hip.lib.mpe_abi_version() == 2
     assert _hip.lib.mpe_desc_sizeof() == ctypes.sizeof(_hip.ScenarioDesc)
 
 
@@ -36,7 +36,10 @@ def _desc(spec):
 
 
 @pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec(),
-                                lambda: O.simple_tag_spec(48, 16, 32), lambda: O.simple_spread_spec(5, 2)])
+                                lambda: O.simple_tag_spec(48, 16, 32), lambda: O.simple_spread_spec(5, 2),
+                                lambda: O.simple_spec(), lambda: O.simple_adversary_spec(),
+                                lambda: O.simple_adversary_spec(5), lambda: O.simple_push_spec(),
+                                lambda: O.simple_push_spec(4, 2, 2)])
 def test_observation_geometry_matches_oracle(mk):
     """KAT-3 through the C ABI's host-only geometry functions."""
     from marl_amd import _hip
@@ -71,13 +74,24 @@ def test_descriptor_validation_and_error_codes():
     assert lib.mpe_desc_check(bad) == -2
     assert lib.mpe_obs_dim(d, 4) == -6
     # launch entry points: validation happens first, so these return without touching a device
-    assert lib.mpe_env_step_f32(d, 0, 0, 8, None, 8, 8, None, None, None, None, None, None) == -3
-    assert lib.mpe_env_step_f32(d, 4, 2, 8, None, 8, 8, None, None, None, None, None, None) == -3
-    assert lib.mpe_env_step_f64(d, 4, 4, None, None, 8, 8, None, None, None, None, None, None) == -1
-    assert lib.mpe_env_step_f64(d, 4, 4, 8, None, 12, 8, None, None, None, None, None, None) == -4
+    assert lib.mpe_env_step_f32(d, 0, 0, 8, None, 8, 8, None, None, None, None, None, None, None) == -3
+    assert lib.mpe_env_step_f32(d, 4, 2, 8, None, 8, 8, None, None, None, None, None, None, None) == -3
+    assert lib.mpe_env_step_f64(d, 4, 4, None, None, 8, 8, None, None, None, None, None, None, None) == -1
+    assert lib.mpe_env_step_f64(d, 4, 4, 8, None, 12, 8, None, None, None, None, None, None, None) == -4
     assert lib.mpe_world_step_f32(d, 4, 4, 8, None, None, 8, None, None) == -1
-    assert lib.mpe_observe_f32(d, 4, 4, 8, 8, None, None, None, None) == -1
-    assert lib.mpe_reset_f32(d, 4, 4, 0, 0, 0, None, None, 8, None, None) == -1
+    assert lib.mpe_observe_f32(d, 4, 4, 8, 8, None, None, None, None, None) == -1
+    assert lib.mpe_reset_f32(d, 4, 4, 0, 0, 0, None, None, 8, None, None, None) == -1
+    # goal scenarios need the goal pointer; scenarios without benchmark_data ignore `info`
+    da = _desc(O.simple_adversary_spec())
+    assert lib.mpe_env_step_f32(da, 4, 4, 8, None, 8, 8, None, None, 8, 8, None, None, None) == -1
+    assert lib.mpe_observe_f64(da, 4, 4, 8, 8, None, 8, None, None, None) == -1
+    ds = _desc(O.simple_spec())
+    assert lib.mpe_observe_f64(ds, 4, 4, 8, 8, None, None, None, 8, None) == -1     # only info asked: nothing to do
+    bad = _hip.ScenarioDesc.from_buffer_copy(da); bad.adversary[1] = 1; bad.adversary[2] = 1
+    assert lib.mpe_desc_check(bad) == -2                                            # no good agent
+    dp = _desc(O.simple_push_spec())
+    bad = _hip.ScenarioDesc.from_buffer_copy(dp); bad.n_landmarks = 3
+    assert lib.mpe_desc_check(bad) == -2                                            # colour index out of range
     assert lib.mpe_stats_reduce(None, 1, 1, None, None) == -1
     assert b'NULL' in lib.mpe_strerror(-1) and b'stride' in lib.mpe_strerror(-3)
     with pytest.raises(_hip.MpeError):
@@ -91,6 +105,8 @@ def test_spaces_and_scenario_loader():
     assert spaces.Box(-np.inf, np.inf, shape=(16,)).shape == (16,)
     tag = scenarios.load('simple_tag.py')
     spread = scenarios.load('simple_spread')
+    for name in ('simple', 'simple_adversary', 'simple_push'):
+        assert hasattr(scenarios.load(name).Scenario, 'make_world')
     assert hasattr(tag.Scenario, 'make_world') and hasattr(spread.Scenario, 'reset_world')
     for name in ('reward', 'observation', 'benchmark_data'):       # multiagent/scenario.py API + make_env.py:40-43
         assert callable(getattr(tag.Scenario, name))
