@@ -36,6 +36,10 @@ WORKLOADS = {
     'scaled_tag_256k_f32': ('simple_tag', dict(num_adversaries=48, num_good_agents=16, num_landmarks=32),
                             1 << 18, torch.float32),                              # BASELINE configs[4]
     'simple_tag_1M_f64': ('simple_tag', {}, 1 << 20, torch.float64),
+    # SURVEY 8f row f1 (same kernels, other gathers)
+    'simple_4M_f32': ('simple', {}, 1 << 22, torch.float32),
+    'simple_adversary_1M_f32': ('simple_adversary', {}, 1 << 20, torch.float32),
+    'simple_push_512k_f32': ('simple_push', {}, 1 << 19, torch.float32),
 }
 
 
@@ -45,7 +49,7 @@ def algorithmic_elems(env, with_info=True):
     w = env.world
     A, E = len(w.agents), len(w.entities)
     obs = sum(s.shape[0] for s in env.observation_space)
-    info_w = w.info.shape[1] if (with_info and w.info is not None) else 0
+    info_w = w.info.shape[1] if (with_info and w.info is not None and env.info_callback is not None) else 0
     return 5 * A + 2 * E + 2 * A + 4 * A + obs + A + A * info_w
 
 
@@ -128,7 +132,8 @@ def main():
     scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[args.workload]
     B = args.envs or envs_per_gpu
     env_id0, _ = shard_range(B * world_size, rank, world_size)      # weak scaling: B per GPU fixed
-    env = make_env(scenario, benchmark=True, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
+    has_info = scenario not in ('simple', 'simple_push')       # those define no benchmark_data
+    env = make_env(scenario, benchmark=has_info, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
     env.world.env_id0 = env_id0
     n = env.n
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -215,7 +220,7 @@ def main():
             'config': {'workload': args.workload, 'scenario': scenario, 'envs_per_gpu': B,
                        'agents': n, 'entities': len(env.world.entities), 'episode_len': EPISODE_LEN,
                        'actions': 'softmax(N(0,1)) soft one-hot, %d resident buffers rotated' % len(pool),
-                       'reset_in_timed_region': True, 'benchmark_info': True,
+                       'reset_in_timed_region': True, 'benchmark_info': has_info,
                        'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
                        'parallelism': 'env-sharded dp%d' % world_size, 'backend': args.backend if world_size > 1 else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
