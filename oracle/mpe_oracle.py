@@ -37,6 +37,7 @@ SIMPLE_SPREAD = 1
 SIMPLE = 2             # build/lib/multiagent/scenarios/simple.py            
 SIMPLE_ADVERSARY = 3   # build/lib/multiagent/scenarios/simple_adversary.py
 SIMPLE_PUSH = 4        # build/lib/multiagent/scenarios/simple_push.py
+HIER_PURSUIT = 5       # multiagent/scenarios/{L1F*,S1L*}.py: the fork's leader/follower pursuit
 GOAL_KINDS = (SIMPLE_ADVERSARY, SIMPLE_PUSH)   # scenarios with a per-env goal landmark (agent.goal_a)
 
 
@@ -63,6 +64,42 @@ class ScenarioSpec:
     damping: float = 0.25                # core.py:102
     contact_force: float = 1e2           # core.py:104
     contact_margin: float = 1e-3         # core.py:105
+    # fork additions (per agent; defaults = stock scenarios): core.py:153-194, L1F2_3Targets_100observe.py:36-86
+    silent: Optional[Sequence[bool]] = None          # non-silent agents carry dim_c comm action entries
+    force_id: Optional[Sequence[int]] = None         # leader gives commands to agents with forced_id == force_id
+    forced_id: Optional[Sequence[int]] = None
+    advleader: Optional[Sequence[bool]] = None
+    advsuperleader: Optional[Sequence[bool]] = None
+    obs_r: Optional[Sequence[float]] = None          # observation radius
+    reward_variant: int = 0                          # 1 = S1L2F2_10Targets_wide_rewardFixed.py
+    n_target_obs: int = 3                            # target_pos[0:3]
+
+    def __post_init__(self):
+        A = self.n_agents
+        if self.silent is None:
+            self.silent = [True] * A
+        if self.force_id is None:
+            self.force_id = [-1] * A
+        if self.forced_id is None:
+            self.forced_id = [-1] * A
+        if self.advleader is None:
+            self.advleader = [False] * A
+        if self.advsuperleader is None:
+            self.advsuperleader = [False] * A
+        if self.obs_r is None:
+            self.obs_r = [0.0] * A
+
+    def act_dim(self, i):
+        """environment.py:42-76: Discrete(5) for silent agents, MultiDiscrete([0,4],[0,dim_c-1]) otherwise."""
+        return 5 + (0 if self.silent[i] else self.dim_c)
+
+    @property
+    def act_dims(self):
+        return [self.act_dim(i) for i in range(self.n_agents)]
+
+    @property
+    def has_leader_force(self):
+        return any(f >= 0 for f in self.forced_id)
 
     @property
     def n_entities(self):
@@ -73,6 +110,8 @@ class ScenarioSpec:
         if self.kind == SIMPLE_TAG:
             n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
             return 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others
+        if self.kind == HIER_PURSUIT:           # L1F2_3Targets_100observe.py:250-253
+            return 4 + 4 * (A - 1) + (2 if self.forced_id[i] >= 0 else 0) + 2 * min(L, self.n_target_obs)
         if self.kind == SIMPLE:                 # simple.py:50
             return 2 + 2 * L
         if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:137-140
@@ -91,7 +130,7 @@ class ScenarioSpec:
             return self.n_landmarks + 1
         if self.kind in (SIMPLE, SIMPLE_PUSH):  # no benchmark_data in these scenarios
             return 0
-        return 1 if self.kind == SIMPLE_TAG else 4
+        return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT) else 4
 
 
 def simple_tag_spec(n_adv=3, n_good=1, n_landmarks=2, u_noise=None):
@@ -120,6 +159,23 @@ def simple_spread_spec(n_agents=3, n_landmarks=3, u_noise=None):
         movable=[True] * A + [False] * n_landmarks,
         u_noise=[u_noise] * A, mass=[1.0] * (A + n_landmarks),
         agent_pos_range=1.0, landmark_pos_range=1.0)
+
+
+def hier_spec_from_golden(g):
+    """ScenarioSpec of an L1F*/S1L* scenario from the world parameters the golden generator read back
+    from the reference's make_world() (tests/golden/gen_golden.py:rollout_hier)."""
+    A = int(g['spec_n_agents'])
+    E = len(g['spec_size'])
+    return ScenarioSpec(
+        kind=HIER_PURSUIT, n_agents=A, n_landmarks=E - A, adversary=[bool(x) for x in g['spec_adversary']],
+        size=[float(x) for x in g['spec_size']], accel=[float(x) for x in g['spec_accel']],
+        max_speed=[float(x) for x in g['spec_max_speed']], collide=[bool(x) for x in g['spec_collide']],
+        movable=[bool(x) for x in g['spec_movable']], u_noise=[None] * A, mass=[1.0] * E,
+        agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=int(g['spec_dim_c']),
+        silent=[bool(x) for x in g['spec_silent']], force_id=[int(x) for x in g['spec_force_id']],
+        forced_id=[int(x) for x in g['spec_forced_id']], advleader=[bool(x) for x in g['spec_advleader']],
+        advsuperleader=[bool(x) for x in g['spec_advsuperleader']], obs_r=[float(x) for x in g['spec_obs_r']],
+        reward_variant=int(g['spec_reward_variant']))
 
 
 def simple_spec():
@@ -155,7 +211,8 @@ def simple_push_spec(n_agents=10, n_adv=9, n_landmarks=1):
 # --------------------------------------------------------------------------------------
 class _Body:
     __slots__ = ('is_agent', 'adversary', 'size', 'accel', 'max_speed', 'collide', 'movable',
-                 'u_noise', 'mass', 'pos', 'vel', 'comm', 'u')
+                 'u_noise', 'mass', 'pos', 'vel', 'comm', 'u', 'c_act', 'silent', 'force_id', 'forced_id',
+                 'advleader', 'advsuperleader', 'obs_r', 'leader_force')
 
 
 class SerialEnv:
@@ -180,6 +237,14 @@ class SerialEnv:
             b.vel = np.zeros(2)
             b.comm = np.zeros(spec.dim_c)
             b.u = np.zeros(2)
+            b.c_act = np.zeros(spec.dim_c)
+            b.silent = bool(spec.silent[e]) if b.is_agent else True
+            b.force_id = spec.force_id[e] if b.is_agent else -1
+            b.forced_id = spec.forced_id[e] if b.is_agent else -1
+            b.advleader = bool(spec.advleader[e]) if b.is_agent else False
+            b.advsuperleader = bool(spec.advsuperleader[e]) if b.is_agent else False
+            b.obs_r = spec.obs_r[e] if b.is_agent else 0.0
+            b.leader_force = np.zeros(2)       # set in make_world, NOT touched by reset_world
             self.bodies.append(b)
         self.agents = self.bodies[:spec.n_agents]
         self.landmarks = self.bodies[spec.n_agents:]
@@ -217,6 +282,43 @@ class SerialEnv:
         u[1] += action[3] - action[4]
         u *= 5.0 if agent.accel is None else agent.accel
         agent.u = u
+        # environment.py:161-168,198-206: a non-silent agent's action carries dim_c comm entries
+        agent.c_act = np.zeros(self.spec.dim_c) if agent.silent else np.asarray(action[5:5 + self.spec.dim_c])
+
+    # -- core.py:153-194 (fork): leaders push the agents they command ------------------------------------
+    def _apply_leader_force(self, force):
+        for i, agent in enumerate(self.agents):
+            agent.leader_force = np.zeros(2)
+            if agent.forced_id < 0:
+                continue
+            for leader in self.agents:
+                if leader.force_id < 0 or agent.forced_id != leader.force_id:
+                    continue
+                if leader.advsuperleader:          # observed only; NOT added to the physical force
+                    agent.leader_force = np.array(leader.c_act[0:2], dtype=np.float64)
+                else:
+                    cmd = int(np.argmax(np.array(leader.c_act)))
+                    if len(leader.c_act) == 3:
+                        cmd = [0, 5, 6][cmd]
+                    f = np.zeros(2)
+                    if cmd == 1:
+                        f = np.array([-1, 0])
+                    elif cmd == 2:
+                        f = np.array([1, 0])
+                    elif cmd == 3:
+                        f = np.array([0, -1])
+                    elif cmd == 4:
+                        f = np.array([0, 1])
+                    elif cmd == 5:
+                        f = leader.pos - agent.pos
+                        f = f / np.linalg.norm(f)
+                    elif cmd == 6:
+                        f = agent.pos - leader.pos
+                        f = f / np.linalg.norm(f)
+                    f = f * 1
+                    force[i] = force[i] + f
+                    agent.leader_force = agent.leader_force + f
+        return force
 
     # -- core.py:124-140 ----------------------------------------------------------------
     def world_step(self):
@@ -227,7 +329,9 @@ class SerialEnv:
             if a.movable:
                 nz = np.random.randn(2) * a.u_noise if a.u_noise else 0.0
                 force[i] = a.u + nz
-        # core.py:153-194 is a no-op for forced_id < 0
+        # core.py:153-194: a no-op for forced_id < 0 (every stock scenario)
+        if s.has_leader_force:
+            force = self._apply_leader_force(force)
         # core.py:197-208 (one-sided: only the lower-indexed entity of a pair is pushed)
         for ia, ea in enumerate(self.bodies):
             for ib in range(ia + 1, len(self.bodies)):
@@ -260,7 +364,80 @@ class SerialEnv:
             e.pos = e.pos + e.vel * s.dt
         # core.py:224-230 (all agents silent)
         for a in self.agents:
-            a.comm = np.zeros(s.dim_c)
+            a.comm = np.zeros(s.dim_c) if a.silent else a.c_act + 0.0
+
+    # -- L1F*/S1L* gathers (e.g. L1F2_3Targets_100observe.py:136-253) ----------------------------------------
+    def _hier_observation(self, i):
+        me = self.agents[i]
+        sq_rad = me.obs_r * me.obs_r
+        other_pos, other_vel, seen, zeros = [], [], [], []
+        for other in self.agents:
+            if other is me:
+                continue
+            sq = np.sum(np.square(other.pos - me.pos))
+            if (sq < sq_rad or (me.force_id >= 0 and me.force_id == other.forced_id)
+                    or (me.forced_id >= 0 and me.forced_id == other.force_id)):
+                other_pos.append(other.pos - me.pos)
+                other_vel.append(other.vel)
+            else:
+                other_pos.append(np.array([0, 0]))
+                other_vel.append(np.array([0, 0]))
+        for lm in self.landmarks:
+            sq = np.sum(np.square(lm.pos - me.pos))
+            if sq < sq_rad:
+                seen.append((sq, lm.pos - me.pos))
+            else:
+                zeros.append(np.array([0, 0]))
+        seen.sort(key=lambda x: x[0])
+        targets = ([p for _, p in seen] + zeros)[0:self.spec.n_target_obs]
+        comm = [me.leader_force] if me.forced_id >= 0 else []
+        return np.concatenate([me.vel] + [me.pos] + other_pos + other_vel + comm + targets)
+
+    def _hier_reward(self, i):
+        me, s = self.agents[i], self.spec
+        r = 0
+        if s.reward_variant == 0:               # L1F2_3Targets_100observe.py:167-181
+            for lm in self.landmarks:
+                if not me.advleader:
+                    if self._touching(lm, me):
+                        r += 10
+                elif not me.advsuperleader:
+                    for o in self.agents:
+                        if o.forced_id == me.force_id and self._touching(lm, o):
+                            r += 10
+                else:
+                    for o in self.agents:
+                        if (not o.advleader) and self._touching(lm, o):
+                            r += 10
+        else:                                   # S1L2F2_10Targets_wide_rewardFixed.py:127-151
+            if me.advsuperleader:
+                for lm in self.landmarks:
+                    for o in self.agents:       # is_observed compares the target with itself: dist = 0
+                        if o.forced_id == me.force_id and 0.0 < o.obs_r:
+                            r += 1
+            elif me.advleader:
+                for lm in self.landmarks:
+                    for o in self.agents:
+                        if o.forced_id == me.force_id and self._touching(lm, o):
+                            r += 10
+            else:
+                for lm in self.landmarks:
+                    if self._touching(lm, me):
+                        r += 10
+        for p in range(2):
+            x = abs(me.pos[p])
+            if x < 0.9:
+                pen = 0
+            elif x < 1.0:
+                pen = (x - 0.9) * 10
+            else:
+                pen = min(np.exp(2 * x - 2), 10)
+            r -= pen
+        return r
+
+    def _hier_info(self, i):                    # L1F2_3Targets_100observe.py:136-148
+        me = self.agents[i]
+        return sum(1 for a in self.agents if a.adversary != me.adversary and self._touching(a, me))
 
     # -- scenario gathers -----------------------------------------------------------------
     @staticmethod
@@ -285,6 +462,8 @@ class SerialEnv:
     def observation(self, i):
         me = self.agents[i]
         kind = self.spec.kind
+        if kind == HIER_PURSUIT:
+            return self._hier_observation(i)
         if kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
             goal = self.landmarks[self.goal]
             rel_lm = [lm.pos - me.pos for lm in self.landmarks]
@@ -315,6 +494,8 @@ class SerialEnv:
     def reward(self, i):
         me = self.agents[i]
         kind = self.spec.kind
+        if kind == HIER_PURSUIT:
+            return self._hier_reward(i)
         if kind == SIMPLE:                                       # simple.py:41-43
             return -self._sq(me, self.landmarks[0])
         if kind in GOAL_KINDS:
@@ -368,6 +549,8 @@ class SerialEnv:
 
     def info(self, i):
         me = self.agents[i]
+        if self.spec.kind == HIER_PURSUIT:
+            return self._hier_info(i)
         if self.spec.kind == SIMPLE_ADVERSARY:                   # simple_adversary.py:58-67
             goal = self.landmarks[self.goal]
             if me.adversary:

@@ -17,6 +17,7 @@ Cases:
       (tag and spread)
   G6  out-of-bounds starts: all four branches of simple_tag bound()
   G7-G9 simple / simple_adversary / simple_push, default and dense starts
+  H*   L1F*/S1L* leader-follower pursuit scenarios of the fork
   KAT known-answer cases 1, 2, 4 of SURVEY.md section 8c
 
 Run:  python tests/golden/gen_golden.py
@@ -77,6 +78,93 @@ TAG = _load(REF + '/build/lib/multiagent/scenarios/simple_tag.py', 'ref_simple_t
 SPREAD = _load(REF + '/build/lib/multiagent/scenarios/simple_spread.py', 'ref_simple_spread')
 OTHER = {k: _load(REF + '/build/lib/multiagent/scenarios/%s.py' % k, 'ref_' + k)
          for k in ('simple', 'simple_adversary', 'simple_push')}
+
+
+HIER_DIR = REF + '/multiagent/scenarios/'          # the fork's live scenarios
+HIER = {}
+
+
+def _hier(name):
+    if name not in HIER:
+        HIER[name] = _load(HIER_DIR + name + '.py', 'ref_' + name)
+    return HIER[name]
+
+
+def build_hier_env(name, seed):
+    """L1F*/S1L* scenarios set force_id / forced_id themselves: no shim needed."""
+    np.random.seed(seed)
+    S = _hier(name).Scenario()
+    world = S.make_world()
+    env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data)
+    return env, world
+
+
+def rollout_hier(name, seeds, T, init=None, actions='rand'):
+    """Like rollout(); actions are ragged (5 physical + dim_c comm entries for non-silent agents,
+    environment.py:161-168) and stored concatenated agent by agent; agent.leader_force recorded."""
+    keys = ('pos0', 'vel0', 'obs0', 'lforce0', 'act', 'pos', 'vel', 'lforce', 'obs', 'rew', 'info')
+    out = {k: [] for k in keys}
+    act_dims = None
+    for seed in seeds:
+        env, world = build_hier_env(name, seed)
+        A = len(world.agents)
+        act_dims = [5 + (0 if a.silent else world.dim_c) for a in world.agents]
+        obs0 = env.reset()
+        if init is not None:
+            init(world, np.random.RandomState(10_000 + seed))
+            obs0 = [env._get_obs(a) for a in env.agents]
+        pos0, vel0 = _state(world)
+        out['lforce0'].append(np.stack([np.asarray(a.leader_force, float) for a in world.agents]))
+        arng = np.random.RandomState(20_000 + seed)
+        ep = {k: [] for k in ('act', 'pos', 'vel', 'lforce', 'obs', 'rew', 'info')}
+        for t in range(T):
+            parts = []
+            for n in act_dims:
+                if actions == 'rand':
+                    parts.append(arng.rand(n))
+                else:                                  # softmax per sub-space (what MADDPG emits)
+                    v = []
+                    for lo, hi in ((0, 5), (5, n)):
+                        if hi > lo:
+                            z = arng.randn(hi - lo) * 2.0
+                            e = np.exp(z - z.max())
+                            v.append(e / e.sum())
+                    parts.append(np.concatenate(v))
+            obs_n, rew_n, done_n, info_n = env.step([p.copy() for p in parts])
+            pos, vel = _state(world)
+            ep['act'].append(np.concatenate(parts))
+            ep['pos'].append(pos.copy())
+            ep['vel'].append(vel.copy())
+            ep['lforce'].append(np.stack([np.asarray(a.leader_force, float).copy() for a in world.agents]))
+            ep['obs'].append(np.concatenate(obs_n))
+            ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
+            ep['info'].append(np.stack([_info_row(x) for x in info_n['n']]))
+        out['pos0'].append(pos0)
+        out['vel0'].append(vel0)
+        out['obs0'].append(np.concatenate(obs0))
+        for k in ep:
+            out[k].append(np.stack(ep[k]))
+    res = {k: np.stack(v) for k, v in out.items()}
+    res['seeds'] = np.asarray(list(seeds))
+    res['act_dims'] = np.asarray(act_dims)
+    # what make_world() set up, read back from the reference's world (the oracle spec is built from these)
+    ents, ags = world.entities, world.agents
+    res['spec_n_agents'] = np.int64(len(ags))
+    res['spec_dim_c'] = np.int64(world.dim_c)
+    res['spec_size'] = np.array([e.size for e in ents], float)
+    res['spec_collide'] = np.array([bool(e.collide) for e in ents])
+    res['spec_movable'] = np.array([bool(e.movable) for e in ents])
+    res['spec_accel'] = np.array([a.accel for a in ags], float)
+    res['spec_max_speed'] = np.array([a.max_speed for a in ags], float)
+    res['spec_silent'] = np.array([bool(a.silent) for a in ags])
+    res['spec_adversary'] = np.array([bool(a.adversary) for a in ags])
+    res['spec_force_id'] = np.array([a.force_id for a in ags], np.int64)
+    res['spec_forced_id'] = np.array([a.forced_id for a in ags], np.int64)
+    res['spec_advleader'] = np.array([bool(a.advleader) for a in ags])
+    res['spec_advsuperleader'] = np.array([bool(a.advsuperleader) for a in ags])
+    res['spec_obs_r'] = np.array([a.obs_r for a in ags], float)
+    res['spec_reward_variant'] = np.int64(1 if 'rewardFixed' in name else 0)
+    return res
 
 
 def _shim(world):
@@ -280,6 +368,12 @@ def main():
     save('g9_simple_push', **rollout('simple_push', range(24), 25))
     save('g9_simple_push_dense', **rollout('simple_push', range(16), 25, init=dense_init,
                                            actions='softmax'))
+    # the fork's leader / follower / super-leader pursuit family
+    for name, n in (('L1F2_3Targets_100observe', 32), ('S1L2F2_3Targets_100observe', 32),
+                    ('L1F2_3Targets_075observe', 8), ('L1F1_10Targets_wide', 16), ('L1F4_3Targets_wide', 16),
+                    ('S1L2F2_10Targets_wide', 16), ('S1L2F2_10Targets_wide_rewardFixed', 16)):
+        save('h_' + name, **rollout_hier(name, range(n), 25, actions='softmax'))
+        save('h_' + name + '_dense', **rollout_hier(name, range(n // 2), 25, init=dense_init))
     kat_cases()
 
 

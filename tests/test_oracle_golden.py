@@ -95,6 +95,61 @@ def test_batched_oracle_bit_exact(golden_dir, name, mk):
         assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1)), (name, t)
 
 
+HIER_CASES = ['h_L1F2_3Targets_100observe', 'h_L1F2_3Targets_100observe_dense',
+              'h_S1L2F2_3Targets_100observe', 'h_S1L2F2_3Targets_100observe_dense',
+              'h_L1F2_3Targets_075observe', 'h_L1F2_3Targets_075observe_dense',
+              'h_L1F1_10Targets_wide', 'h_L1F1_10Targets_wide_dense',
+              'h_L1F4_3Targets_wide', 'h_L1F4_3Targets_wide_dense',
+              'h_S1L2F2_10Targets_wide', 'h_S1L2F2_10Targets_wide_dense',
+              'h_S1L2F2_10Targets_wide_rewardFixed', 'h_S1L2F2_10Targets_wide_rewardFixed_dense']
+
+
+def _split_actions(g, s, t):
+    dims = g['act_dims']
+    offs = np.concatenate([[0], np.cumsum(dims)])
+    return [g['act'][s, t, offs[i]:offs[i + 1]] for i in range(len(dims))]
+
+
+@pytest.mark.parametrize('name', HIER_CASES)
+def test_serial_oracle_hier_bit_exact(golden_dir, name):
+    """leader force (core.py:153-194), masked / distance-sorted observations and
+    hierarchical rewards of the fork's L1F*/S1L* scenarios."""
+    g = _load(golden_dir, name)
+    spec = O.hier_spec_from_golden(g)
+    assert spec.act_dims == list(g['act_dims'])
+    S, T = g['act'].shape[:2]
+    for s in range(min(S, 8)):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        for a, lf in zip(env.agents, g['lforce0'][s]):
+            a.leader_force = lf.copy()
+        assert np.array_equal(np.concatenate([env.observation(i) for i in range(env.n)]), g['obs0'][s])
+        for t in range(T):
+            obs_n, rew_n, done_n, info_n = env.step(_split_actions(g, s, t))
+            pos, vel = env.get_state()
+            assert np.array_equal(pos, g['pos'][s, t]), (name, s, t)
+            assert np.array_equal(vel, g['vel'][s, t]), (name, s, t)
+            assert np.array_equal(np.stack([a.leader_force for a in env.agents]), g['lforce'][s, t]), (name, s, t)
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
+            assert np.array_equal(np.asarray(rew_n, float), g['rew'][s, t]), (name, s, t)
+            assert np.array_equal(np.asarray(info_n['n'], float)[:, None], g['info'][s, t]), (name, s, t)
+
+
+def test_hier_goldens_exercise_the_branches(golden_dir):
+    g = _load(golden_dir, 'h_S1L2F2_3Targets_100observe_dense')
+    assert (g['rew'] >= 10).any()                                        # landmark contacts
+    assert (np.abs(g['lforce'][:, :, :2]) > 0).any()                      # followers are pushed
+    lf = g['lforce'][:, :, 2:4]                                           # leaders observe the super-leader's c[0:2]
+    assert ((lf >= 0) & (lf <= 1)).all() and (lf > 0).any()
+    spec = O.hier_spec_from_golden(g)
+    n_t = 2 * min(spec.n_landmarks, 3)
+    tail = g['obs'][:, :, spec.obs_dim(0) - n_t:spec.obs_dim(0)]          # follower 0's target slots
+    assert (tail != 0).any() and (tail == 0).any()                        # some visible, some masked
+    g = _load(golden_dir, 'h_S1L2F2_10Targets_wide_rewardFixed')
+    r = g['rew'][:, :, 4]           # is_observed() compares a target with itself: constant +1 per (target, leader)
+    assert r.max() == 20.0 and (r <= 20.0).all() and (r == 20.0).mean() > 0.5
+
+
 def test_golden_cases_exercise_the_branches(golden_dir):
     """The dense / out-of-bounds fixtures really hit collisions, the clamp and all bound() arms."""
     g = _load(golden_dir, 'g5_simple_tag_dense')
