@@ -593,6 +593,24 @@ class SerialEnv:
 # --------------------------------------------------------------------------------------
 # Batched restatement (SoA, vectorised over envs, same per-element operation order)
 # --------------------------------------------------------------------------------------
+def _norm2_blas(d0, d1):
+    """np.linalg.norm of a 2-vector as the reference computes it (core.py:185,188): sqrt(dot(x, x)), and
+    this container's BLAS dot rounds as fma(x1, x1, x0*x0) (checked against np.linalg.norm on 20 000
+    random vectors).  Emulated with error-free transformations so that it vectorises."""
+    d0 = np.asarray(d0, np.float64)
+    d1 = np.asarray(d1, np.float64)
+    s = d0 * d0
+    p = d1 * d1
+    c = 134217729.0 * d1                       # Veltkamp split of d1 (2^27 + 1)
+    hi = c - (c - d1)
+    lo = d1 - hi
+    e = ((hi * hi - p) + 2.0 * hi * lo) + lo * lo          # d1*d1 == p + e exactly
+    h = p + s                                              # TwoSum(p, s) == h + l exactly
+    z = h - p
+    l = (p - (h - z)) + (s - z)
+    return np.sqrt(h + (l + e))
+
+
 class BatchedOracle:
     """pos[E,2,B], vel[A,2,B]; act[A,5,B]; noise[A,2,B] standard normals (or None)."""
 
@@ -600,21 +618,63 @@ class BatchedOracle:
         self.spec = spec
         self.dt = np.dtype(dtype).type
 
-    def world_step(self, pos, vel, act, noise=None):
+    def _leader_force(self, pos, act, force):
+        """core.py:153-194, vectorised; returns lforce [A,2,B] (agent.leader_force after the step)."""
+        s, T = self.spec, self.dt
+        A = s.n_agents
+        B = pos.shape[-1]
+        offs = np.concatenate([[0], np.cumsum(s.act_dims)])
+        lf = np.zeros((A, 2, B), T)
+        for i in range(A):
+            if s.forced_id[i] < 0:
+                continue
+            for l in range(A):
+                if s.force_id[l] < 0 or s.forced_id[i] != s.force_id[l]:
+                    continue
+                c = act[offs[l] + 5:offs[l] + 5 + s.dim_c]
+                if s.advsuperleader[l]:
+                    lf[i] = c[0:2]
+                    continue
+                cmd = np.argmax(c, axis=0)
+                if s.dim_c == 3:
+                    cmd = np.array([0, 5, 6])[cmd]
+                f = np.zeros((2, B), T)
+                f[0] = np.where(cmd == 1, T(-1), np.where(cmd == 2, T(1), T(0)))
+                f[1] = np.where(cmd == 3, T(-1), np.where(cmd == 4, T(1), T(0)))
+                norm = _norm2_blas if T is np.float64 else (lambda a, b: np.sqrt(a * a + b * b))
+                d = pos[l] - pos[i]
+                unit = d / norm(d[0], d[1])
+                f = np.where(cmd == 5, unit, f)
+                d = pos[i] - pos[l]
+                unit = d / norm(d[0], d[1])
+                f = np.where(cmd == 6, unit, f)
+                force[i] = force[i] + f
+                lf[i] = lf[i] + f
+        return lf
+
+    def world_step(self, pos, vel, act, noise=None, return_lforce=False):
+        """act: [A,5,B] (all agents silent) or ragged rows [sum(act_dims), B] (environment.py:161-168)."""
         s, T = self.spec, self.dt
         A, E = s.n_agents, s.n_entities
         pos = np.array(pos, dtype=T)
         vel = np.array(vel, dtype=T)
         act = np.asarray(act, dtype=T)
+        if act.ndim == 3:
+            act = act.reshape(-1, act.shape[-1])
+        offs = np.concatenate([[0], np.cumsum(s.act_dims)])
         force = [None] * E
+        lforce = None
         with np.errstate(all='ignore'):
             for i in range(A):
                 sens = T(5.0 if s.accel[i] is None else s.accel[i])
-                u = np.stack([(act[i, 1] - act[i, 2]) * sens, (act[i, 3] - act[i, 4]) * sens])
+                a = act[offs[i]:offs[i] + 5]
+                u = np.stack([(a[1] - a[2]) * sens, (a[3] - a[4]) * sens])
                 if s.movable[i]:
                     if s.u_noise[i]:
                         u = u + np.asarray(noise[i], dtype=T) * T(s.u_noise[i])
                     force[i] = u
+            if s.has_leader_force:
+                lforce = self._leader_force(pos, act, force)
             k = T(s.contact_margin)
             cf = T(s.contact_force)
             for a in range(E):
@@ -642,7 +702,80 @@ class BatchedOracle:
                     v = np.where(speed > ms, clamped, v)
                 vel[i] = v
                 pos[i] = pos[i] + v * T(s.dt)
+        if return_lforce:
+            return pos, vel, (lforce if lforce is not None else np.zeros((A, 2, pos.shape[-1]), T))
         return pos, vel
+
+    def _observe_hier(self, pos, vel, lforce):
+        """L1F*/S1L* gathers, vectorised (e.g. L1F2_3Targets_100observe.py:136-253)."""
+        s, T = self.spec, self.dt
+        A, L = s.n_agents, s.n_landmarks
+        B = pos.shape[-1]
+        sq = lambda p, q: np.square(p[0] - q[0]) + np.square(p[1] - q[1])
+        touch = lambda e, f: np.sqrt(sq(pos[e], pos[f])) < T(s.size[e] + s.size[f])
+        obs, rew, info = [], np.zeros((A, B), T), np.zeros((A, 1, B), T)
+        with np.errstate(all='ignore'):
+            for i in range(A):
+                sq_rad = T(s.obs_r[i]) * T(s.obs_r[i])
+                rows = [vel[i], pos[i]]
+                vis = []
+                for j in range(A):
+                    if j == i:
+                        continue
+                    linked = ((s.force_id[i] >= 0 and s.force_id[i] == s.forced_id[j])
+                              or (s.forced_id[i] >= 0 and s.forced_id[i] == s.force_id[j]))
+                    v = np.ones(B, bool) if linked else (sq(pos[j], pos[i]) < sq_rad)
+                    vis.append((j, v))
+                    rows.append(np.where(v, pos[j] - pos[i], T(0)))
+                rows += [np.where(v, vel[j], T(0)) for j, v in vis]
+                if s.forced_id[i] >= 0:
+                    rows.append(lforce[i])
+                if L:
+                    d2 = np.stack([sq(pos[A + l], pos[i]) for l in range(L)])          # [L,B]
+                    seen = d2 < sq_rad
+                    order = np.argsort(np.where(seen, d2, np.inf), axis=0, kind='stable')
+                    rel = np.stack([pos[A + l] - pos[i] for l in range(L)])              # [L,2,B]
+                    for k in range(min(L, s.n_target_obs)):
+                        idx = order[k]
+                        pick = rel[idx, :, np.arange(B)].T                              # [2,B]
+                        rows.append(np.where(seen[idx, np.arange(B)], pick, T(0)))
+                obs.append(np.concatenate(rows, axis=0))
+                # reward
+                r = np.zeros(B, T)
+                if s.reward_variant == 0:
+                    for l in range(L):
+                        if not s.advleader[i]:
+                            r = r + T(10) * touch(A + l, i)
+                        elif not s.advsuperleader[i]:
+                            for o in range(A):
+                                if s.forced_id[o] == s.force_id[i]:
+                                    r = r + T(10) * touch(A + l, o)
+                        else:
+                            for o in range(A):
+                                if not s.advleader[o]:
+                                    r = r + T(10) * touch(A + l, o)
+                else:
+                    for l in range(L):
+                        for o in range(A):
+                            if s.advsuperleader[i]:
+                                if s.forced_id[o] == s.force_id[i] and 0.0 < s.obs_r[o]:
+                                    r = r + T(1)
+                            elif s.advleader[i]:
+                                if s.forced_id[o] == s.force_id[i]:
+                                    r = r + T(10) * touch(A + l, o)
+                        if not s.advleader[i]:
+                            r = r + T(10) * touch(A + l, i)
+                for p in range(2):
+                    x = np.abs(pos[i, p])
+                    bnd = np.where(x < T(0.9), T(0),
+                                   np.where(x < T(1.0), (x - T(0.9)) * T(10),
+                                            np.minimum(np.exp(T(2) * x - T(2)), T(10))))
+                    r = r - bnd
+                rew[i] = r
+                for a in range(A):
+                    if s.adversary[a] != s.adversary[i]:
+                        info[i, 0] += touch(a, i)
+        return obs, rew, info
 
     def _dist(self, pos, i, j):
         d = pos[i] - pos[j]
@@ -709,13 +842,17 @@ class BatchedOracle:
                         rew[i] = -np.sqrt(sq(pos[i], gp))
         return obs, rew, info
 
-    def observe(self, pos, vel, want_info=True, goal=None):
+    def observe(self, pos, vel, want_info=True, goal=None, lforce=None):
         """Returns obs (list of [dim_i, B]), rew [A,B], info [A,W,B]."""
         s, T = self.spec, self.dt
         A, L, E = s.n_agents, s.n_landmarks, s.n_entities
         B = pos.shape[-1]
         pos = np.asarray(pos, dtype=T)
         vel = np.asarray(vel, dtype=T)
+        if s.kind == HIER_PURSUIT:
+            lforce = np.zeros((A, 2, B), T) if lforce is None else np.asarray(lforce, T)
+            obs, rew, info = self._observe_hier(pos, vel, lforce)
+            return obs, rew, (info if want_info else None)
         if s.kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
             obs, rew, info = self._observe_f1(pos, vel, goal)
             return obs, rew, (info if want_info else None)
@@ -776,9 +913,11 @@ class BatchedOracle:
                     info[i, 0], info[i, 1], info[i, 2], info[i, 3] = r, c, md, occ
         return obs, rew, (info if want_info else None)
 
-    def env_step(self, pos, vel, act, noise=None, goal=None):
-        pos, vel = self.world_step(pos, vel, act, noise)
-        obs, rew, info = self.observe(pos, vel, goal=goal)
+    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False):
+        pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True)
+        obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce)
+        if return_lforce:
+            return pos, vel, obs, rew, info, lforce
         return pos, vel, obs, rew, info
 
 

@@ -135,6 +135,26 @@ def test_serial_oracle_hier_bit_exact(golden_dir, name):
             assert np.array_equal(np.asarray(info_n['n'], float)[:, None], g['info'][s, t]), (name, s, t)
 
 
+@pytest.mark.parametrize('name', HIER_CASES)
+def test_batched_oracle_hier_bit_exact(golden_dir, name):
+    g = _load(golden_dir, name)
+    spec = O.hier_spec_from_golden(g)
+    S, T = g['act'].shape[:2]
+    bo = O.BatchedOracle(spec)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    obs, _, _ = bo.observe(pos, vel, lforce=np.moveaxis(g['lforce0'], 0, -1))
+    assert np.array_equal(np.concatenate(obs, 0), g['obs0'].T)
+    for t in range(T):
+        pos, vel, obs, rew, info, lf = bo.env_step(pos, vel, g['act'][:, t].T, return_lforce=True)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(lf, np.moveaxis(g['lforce'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+        assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1)), (name, t)
+
+
 def test_hier_goldens_exercise_the_branches(golden_dir):
     g = _load(golden_dir, 'h_S1L2F2_3Targets_100observe_dense')
     assert (g['rew'] >= 10).any()                                        # landmark contacts
