@@ -11,8 +11,9 @@
  * binding; INTEGRATION.md shows the stub a maintainer of the reference would add).
  *
  * Conventions
- *   - Plain C, plain pointers and sizes.  All array arguments are DEVICE pointers unless the name
- *     starts with h_.  The library allocates nothing, keeps no global state, never synchronises:
+ *   - Plain C, plain pointers and sizes.  All array arguments (the members of mpe_buffers, `mask`,
+ *     the stats vectors) are DEVICE pointers; mpe_scenario_desc and mpe_buffers themselves live in
+ *     host memory and are read during the call only.  The library allocates nothing, keeps no global state, never synchronises:
  *     every call only enqueues kernels on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream).  Safe to call concurrently from several threads / processes on different devices.
  *   - Return value: 0 = OK, < 0 = MPE_ERR_* (bad argument; nothing was launched), > 0 = hipError_t
@@ -20,7 +21,8 @@
  *   - Struct-of-arrays device layout, env index fastest ("row" = one scalar for all envs):
  *         pos  [E][2][ld]    E = n_agents + n_landmarks, agents first (core.py:109-111)
  *         vel  [A][2][ld]    landmarks never move in the supported scenarios
- *         act  [A][5][ld]    soft one-hot Discrete(5) action (environment.py:188-190)
+ *         act  [act_total][ld]  soft one-hot Discrete(5) action per agent (environment.py:188-190),
+ *                            [A][5][ld] when every agent is silent; see mpe_buffers
  *         noise[A][2][ld]    standard normals for u_noise (core.py:147); may be NULL
  *         comm [A][dim_c][ld]  agent.state.c, written as zeros (all agents silent, core.py:226-227);
  *                              may be NULL (then not written)
@@ -48,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 2
+#define MPE_ABI_VERSION 3
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -58,6 +60,9 @@ extern "C" {
 #define MPE_SIMPLE 2        /* build/lib/multiagent/scenarios/simple.py            */
 #define MPE_SIMPLE_ADVERSARY 3 /* build/lib/multiagent/scenarios/simple_adversary.py (per-env goal) */
 #define MPE_SIMPLE_PUSH 4   /* build/lib/multiagent/scenarios/simple_push.py      (per-env goal) */
+#define MPE_HIER_PURSUIT 5  /* multiagent/scenarios/L1F..py and S1L..py: the fork's follower / leader /
+                               super-leader pursuit family (leader force core.py:153-194, masked +
+                               distance-sorted observations, hierarchical rewards)               */
 
 /* error codes */
 #define MPE_OK 0
@@ -94,7 +99,43 @@ typedef struct mpe_scenario_desc {
   uint8_t movable[MPE_MAX_ENTITIES];
   uint8_t collide[MPE_MAX_ENTITIES];
   uint8_t adversary[MPE_MAX_AGENTS]; /* simple_tag: agent.adversary (simple_tag.py:21)        */
+  /* fork additions (L1F2_3Targets_100observe.py:36-86); stock scenarios: silent = 1, ids = -1 */
+  uint8_t silent[MPE_MAX_AGENTS];    /* 0: the agent's action carries dim_c comm entries after the
+                                        5 physical ones (MultiDiscrete, environment.py:61-69,161-168) */
+  int8_t force_id[MPE_MAX_AGENTS];   /* >= 0: commands the agents whose forced_id equals it
+                                        (core.py:157-160)                                       */
+  int8_t forced_id[MPE_MAX_AGENTS];  /* >= 0: is commanded; -1: none                            */
+  uint8_t advleader[MPE_MAX_AGENTS];
+  uint8_t advsuperleader[MPE_MAX_AGENTS]; /* its command is the raw c[0:2], observed not applied
+                                             (core.py:162-163)                                  */
+  int32_t reward_variant;            /* 0: L1F.. / S1L.. default; 1: S1L2F2_10Targets_wide_rewardFixed */
+  int32_t n_target_obs;              /* target_pos[0:n] in the observation (3)                  */
+  double obs_r[MPE_MAX_AGENTS];      /* agent.obs_r: observation radius                         */
 } mpe_scenario_desc;
+
+/*
+ * Device buffers of one batch (struct-of-arrays, see the layout list above).  Element type of the
+ * void pointers = the _f32 / _f64 suffix of the function called.  Which members a call reads or
+ * writes is stated at each function; members it does not use may be NULL.
+ *   act    [act_total][ld]   agent i owns rows [act_row0(i), act_row0(i)+act_dim(i)): 5 physical
+ *                            entries, then dim_c comm entries when the agent is not silent
+ *   lforce [A][2][ld]        agent.leader_force (core.py:156-192): written by every world step,
+ *                            read by the HIER_PURSUIT observation; NOT touched by reset (like the
+ *                            reference's reset_world).  Required when any forced_id >= 0.
+ */
+typedef struct mpe_buffers {
+  const void *act;
+  const void *noise; /* [A][2][ld] standard normals for u_noise, or NULL */
+  void *pos;         /* [E][2][ld] */
+  void *vel;         /* [A][2][ld] */
+  void *comm;        /* [A][dim_c][ld] agent.state.c, or NULL (then not written) */
+  void *lforce;
+  int32_t *goal;     /* [ld] goal landmark index (simple_adversary / simple_push) */
+  void *obs;         /* [obs_total][ld] */
+  void *rew;         /* [A][ld] */
+  void *info;        /* [A][info_w][ld] */
+  double *stats;     /* [mpe_stats_rows][mpe_stats_width] or NULL */
+} mpe_buffers;
 
 int mpe_abi_version(void);
 const char *mpe_strerror(int code);
@@ -110,47 +151,46 @@ int mpe_obs_dim(const mpe_scenario_desc *desc, int agent);
 int mpe_obs_row0(const mpe_scenario_desc *desc, int agent);
 int mpe_obs_total(const mpe_scenario_desc *desc);
 int mpe_info_width(const mpe_scenario_desc *desc);
+/* Action geometry: 5 (+ dim_c for non-silent agents) entries per agent (environment.py:42-76). */
+int mpe_act_dim(const mpe_scenario_desc *desc, int agent);
+int mpe_act_row0(const mpe_scenario_desc *desc, int agent);
+int mpe_act_total(const mpe_scenario_desc *desc);
 
 /*
  * World.step for every env (core.py:124-140): MultiAgentEnv._set_action decode
- * (environment.py:157-208) -> apply_action_force (core.py:143-149) -> apply_environment_force /
- * get_collision_force (core.py:197-208, 233-249; this fork's one-sided response) ->
- * integrate_state (core.py:211-222) -> update_agent_state (core.py:224-230).
- * pos / vel are updated in place.
+ * (environment.py:157-208) -> apply_action_force (core.py:143-149) -> apply_leader_force
+ * (core.py:153-194) -> apply_environment_force / get_collision_force (core.py:197-208, 233-249;
+ * this fork's one-sided response) -> integrate_state (core.py:211-222) -> update_agent_state
+ * (core.py:224-230).  Reads act, noise; updates pos, vel in place; writes lforce, comm.
  */
-int mpe_world_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *act,
-                       const float *noise, float *pos, float *vel, float *comm, void *stream);
-int mpe_world_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *act,
-                       const double *noise, double *pos, double *vel, double *comm, void *stream);
+int mpe_world_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
+                       void *stream);
+int mpe_world_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
+                       void *stream);
 
 /*
  * Scenario gathers from the current state, for every agent of every env:
  * observation (simple_tag.py:131-147 / simple_spread.py:83-99), reward (simple_tag.py:84-129 /
  * simple_spread.py:71-81), benchmark_data (simple_tag.py:57-66 / simple_spread.py:46-62); for the
- * other kinds simple.py:41-50, simple_adversary.py:58-140, simple_push.py:66-104.
- * Any of obs / rew / info may be NULL (skipped); MultiAgentEnv.reset() needs obs only
- * (environment.py:119-129).
+ * other kinds simple.py:41-50, simple_adversary.py:58-140, simple_push.py:66-104,
+ * L1F2_3Targets_100observe.py:136-253.  Reads pos, vel, goal, lforce; writes whichever of obs /
+ * rew / info is not NULL (MultiAgentEnv.reset() needs obs only, environment.py:119-129).
  */
-int mpe_observe_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *pos,
-                    const float *vel, const int32_t *goal, float *obs, float *rew, float *info,
+int mpe_observe_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
                     void *stream);
-int mpe_observe_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *pos,
-                    const double *vel, const int32_t *goal, double *obs, double *rew, double *info,
+int mpe_observe_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
                     void *stream);
 
 /*
  * MultiAgentEnv.step (environment.py:92-117) in one launch: mpe_world_step followed by
  * mpe_observe on the post-step state, with the state kept on chip in between.
- * `stats` (may be NULL): per-workgroup running sums of reward / collision statistics, double
+ * buf->stats (may be NULL): per-workgroup running sums of reward / collision statistics, double
  * [mpe_stats_rows(...)][mpe_stats_width(desc)], accumulated (+=) by this call; reduce with
  * mpe_stats_reduce.  Zero it with hipMemsetAsync before the first step of a window.
  */
-int mpe_env_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const float *act,
-                     const float *noise, float *pos, float *vel, float *comm, const int32_t *goal,
-                     float *obs, float *rew, float *info, double *stats, void *stream);
-int mpe_env_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const double *act,
-                     const double *noise, double *pos, double *vel, double *comm,
-                     const int32_t *goal, double *obs, double *rew, double *info, double *stats,
+int mpe_env_step_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
+                     void *stream);
+int mpe_env_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
                      void *stream);
 
 /*
@@ -159,15 +199,16 @@ int mpe_env_step_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const
  * np.random stream; this build draws Philox4x32-10 with counter (env_id_lo, env_id_hi, episode,
  * entity) and key = seed, env_id = env_id0 + index, so results do not depend on how envs are
  * sharded over GPUs.  `mask` (may be NULL): uint8 [B], only envs with mask != 0 are reset.
- * `goal` (may be NULL): the goal landmark of each env is drawn uniformly from the same stream
- * (entity word 0xFFFFFFFF; np.random.choice(world.landmarks) in the reference).
+ * Writes buf->pos, vel, comm (if not NULL) and goal (if not NULL: the goal landmark of each env,
+ * drawn uniformly from the same stream at entity word 0xFFFFFFFF; np.random.choice(
+ * world.landmarks) in the reference).
  */
 int mpe_reset_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
-                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, float *pos, float *vel,
-                  float *comm, int32_t *goal, void *stream);
+                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, const mpe_buffers *buf,
+                  void *stream);
 int mpe_reset_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
-                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, double *pos,
-                  double *vel, double *comm, int32_t *goal, void *stream);
+                  uint32_t episode, uint64_t env_id0, const uint8_t *mask, const mpe_buffers *buf,
+                  void *stream);
 
 /*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,

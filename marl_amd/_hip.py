@@ -19,8 +19,9 @@ MPE_SIMPLE_SPREAD = 1
 MPE_SIMPLE = 2
 MPE_SIMPLE_ADVERSARY = 3
 MPE_SIMPLE_PUSH = 4
+MPE_HIER_PURSUIT = 5
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -39,7 +40,33 @@ class ScenarioDesc(C.Structure):
         ('u_noise', C.c_double * MPE_MAX_AGENTS),
         ('movable', C.c_uint8 * MPE_MAX_ENTITIES), ('collide', C.c_uint8 * MPE_MAX_ENTITIES),
         ('adversary', C.c_uint8 * MPE_MAX_AGENTS),
+        ('silent', C.c_uint8 * MPE_MAX_AGENTS),
+        ('force_id', C.c_int8 * MPE_MAX_AGENTS), ('forced_id', C.c_int8 * MPE_MAX_AGENTS),
+        ('advleader', C.c_uint8 * MPE_MAX_AGENTS), ('advsuperleader', C.c_uint8 * MPE_MAX_AGENTS),
+        ('reward_variant', C.c_int32), ('n_target_obs', C.c_int32),
+        ('obs_r', C.c_double * MPE_MAX_AGENTS),
     ]
+
+
+class Buffers(C.Structure):
+    """mpe_buffers (include/mpe_hip.h): device pointers of one batch."""
+    _fields_ = [(n, C.c_void_p) for n in ('act', 'noise', 'pos', 'vel', 'comm', 'lforce', 'goal', 'obs', 'rew',
+                                          'info', 'stats')]
+
+    def __init__(self, **tensors):
+        super().__init__()
+        self.set(**tensors)
+
+    def set(self, **tensors):
+        """Members from tensors (None -> NULL)."""
+        for name, t in tensors.items():
+            if name not in _BUFFER_NAMES:
+                raise AttributeError('mpe_buffers has no member %r' % name)
+            setattr(self, name, None if t is None else t.data_ptr())
+        return self
+
+
+_BUFFER_NAMES = frozenset(n for n, _ in Buffers._fields_)
 
 
 class MpeError(RuntimeError):
@@ -61,21 +88,19 @@ def _load():
     L.mpe_abi_version.argtypes = []
     L.mpe_strerror.restype = C.c_char_p
     L.mpe_strerror.argtypes = [ci]
-    for name in ('mpe_desc_check', 'mpe_obs_total', 'mpe_info_width', 'mpe_stats_width'):
+    bp = C.POINTER(Buffers)
+    for name in ('mpe_desc_check', 'mpe_obs_total', 'mpe_info_width', 'mpe_stats_width', 'mpe_act_total'):
         f = getattr(L, name)
         f.restype, f.argtypes = ci, [dp]
-    for name in ('mpe_obs_dim', 'mpe_obs_row0'):
+    for name in ('mpe_obs_dim', 'mpe_obs_row0', 'mpe_act_dim', 'mpe_act_row0'):
         f = getattr(L, name)
         f.restype, f.argtypes = ci, [dp, ci]
     for suf in ('f32', 'f64'):
-        f = getattr(L, 'mpe_world_step_' + suf)
-        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp]
-        f = getattr(L, 'mpe_observe_' + suf)          # desc, B, ld, pos, vel, goal, obs, rew, info, stream
-        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
-        f = getattr(L, 'mpe_env_step_' + suf)         # ..., act, noise, pos, vel, comm, goal, obs, rew, info, stats, stream
-        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-        f = getattr(L, 'mpe_reset_' + suf)            # ..., seed, episode, env_id0, mask, pos, vel, comm, goal, stream
-        f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, vp, vp, vp, vp, vp]
+        for name in ('mpe_world_step_', 'mpe_observe_', 'mpe_env_step_'):   # desc, B, ld, buffers, stream
+            f = getattr(L, name + suf)
+            f.restype, f.argtypes = ci, [dp, i64, i64, bp, vp]
+        f = getattr(L, 'mpe_reset_' + suf)            # desc, B, ld, seed, episode, env_id0, mask, buffers, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, bp, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci]
     L.mpe_stats_reduce.restype = ci
@@ -84,11 +109,11 @@ def _load():
     L.mpe_debug_force_tile_kernel.argtypes = [ci]
     L.mpe_desc_sizeof.restype = i64
     L.mpe_desc_sizeof.argtypes = []
+    if L.mpe_abi_version() != ABI_VERSION:
+        raise ImportError('marl_amd: libmpe_hip.so ABI %d != expected %d' % (L.mpe_abi_version(), ABI_VERSION))
     if L.mpe_desc_sizeof() != C.sizeof(ScenarioDesc):
         raise ImportError('marl_amd: mpe_scenario_desc layout mismatch (%d vs %d bytes)'
                           % (L.mpe_desc_sizeof(), C.sizeof(ScenarioDesc)))
-    if L.mpe_abi_version() != ABI_VERSION:
-        raise ImportError('marl_amd: libmpe_hip.so ABI %d != expected %d' % (L.mpe_abi_version(), ABI_VERSION))
     return L
 
 

@@ -4,7 +4,10 @@ per-entity numpy arrays replaced by struct-of-arrays device tensors shared by al
     world.pos  [E, 2, B]   entities = agents then landmarks (core.py:109-111)
     world.vel  [A, 2, B]
     world.comm [A, dim_c, B]
-    world.act  [A, 5, B]   soft one-hot Discrete(5) actions (environment.py:188-190)
+    world.act  [A, 5, B]   soft one-hot Discrete(5) actions (environment.py:188-190); with non-silent
+                           agents (MultiDiscrete, environment.py:61-69) ragged rows [act_total, B]:
+                           agent i owns rows act_row0[i] .. +5 (+dim_c comm entries)
+    world.lforce [A, 2, B] agent.leader_force (core.py:156-192), worlds with a command hierarchy only
 
 ``entity.state.p_pos`` / ``p_vel`` / ``agent.state.c`` are ``[B, 2]`` views into those buffers
 (strides (1, B)), so reference-style scenario code keeps working on whole batches.
@@ -123,6 +126,28 @@ class Agent(Entity):
         self.state = AgentState(self)
         self.action = Action()
         self.action_callback = None
+        # fork's command hierarchy (set by the L1F*/S1L* scenarios, L1F2_3Targets_100observe.py:36-70)
+        self.adversary = False
+        self.advleader = False
+        self.advsuperleader = False
+        self.force_id = -1
+        self.forced_id = -1
+
+    @property
+    def leader_force(self):
+        """[B, 2] view of this agent's row pair in world.lforce (core.py:156)."""
+        w = self._world
+        if w is None or w.lforce is None:
+            return None
+        return w.lforce[self._index].t()
+
+    @leader_force.setter
+    def leader_force(self, value):
+        w = self._world
+        if w is not None and w.lforce is not None:
+            r = w.lforce[self._index]
+            r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], 2).t())
+            w.mark_dirty()
 
 
 class World(object):
@@ -142,7 +167,9 @@ class World(object):
         self.num_envs = 0
         self.device = None
         self.dtype = None
-        self.pos = self.vel = self.comm = self.act = self.noise = None
+        self.pos = self.vel = self.comm = self.act = self.noise = self.lforce = None
+        self.act_rows = None       # [act_total, B]: the action buffer as the kernel indexes it
+        self.act_row0 = self.act_dims = None
         self.goal = None           # int32 [B]: goal landmark index (agent.goal_a), goal scenarios only
         # gather outputs (allocated on first use): obs [obs_total,B], rew [A,B], info [A,W,B]
         self.obs = self.rew = self.info = None
@@ -189,13 +216,20 @@ class World(object):
         self.pos = torch.zeros(E, 2, B, **z)
         self.vel = torch.zeros(A, 2, B, **z)
         self.comm = torch.zeros(A, max(self.dim_c, 1), B, **z)[:, :self.dim_c]
-        self.act = torch.zeros(A, 5, B, **z)
+        # action rows (environment.py:42-76): 5 physical entries, + dim_c comm entries if not silent
+        self.act_dims = [5 + (0 if a.silent else self.dim_c) for a in self.agents]
+        self.act_row0 = [sum(self.act_dims[:i]) for i in range(A)]
+        self.act_rows = torch.zeros(sum(self.act_dims), B, **z)
+        self.act = self.act_rows.view(A, 5, B) if all(a.silent for a in self.agents) else self.act_rows
+        self.lforce = torch.zeros(A, 2, B, **z) if any(a.forced_id >= 0 for a in self.agents) else None
         self.goal = torch.zeros(B, dtype=torch.int32, device=device)
         self.noise = None
         self.obs = self.rew = self.info = self.obs_views = self.stats = None
         for i, e in enumerate(self.entities):
             e._world, e._index = self, i
         self._desc = None
+        self._buf = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal,
+                                 comm=self.comm if (self.dim_c and not all(a.silent for a in self.agents)) else None)
         self.mark_dirty()
         return self
 
@@ -211,6 +245,7 @@ class World(object):
         self.obs = torch.zeros(total, B, **z)
         self.rew = torch.zeros(A, B, **z)
         self.info = torch.zeros(A, _hip.lib.mpe_info_width(d), B, **z)
+        self._buf.set(obs=self.obs, rew=self.rew)
         self.obs_views = []
         for i in range(A):
             r0, n = _hip.lib.mpe_obs_row0(d, i), _hip.lib.mpe_obs_dim(d, i)
@@ -224,9 +259,8 @@ class World(object):
             return
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
-        _hip.check(fn(d, self.num_envs, self.num_envs, self.pos.data_ptr(), self.vel.data_ptr(),
-                      self.goal.data_ptr(), self.obs.data_ptr(), None, None, _hip.stream_of(self.device)),
-                   'mpe_observe')
+        b = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, obs=self.obs)
+        _hip.check(fn(d, self.num_envs, self.num_envs, b, _hip.stream_of(self.device)), 'mpe_observe')
         self._obs_tick = self._tick
 
     def gather(self, force=False):
@@ -238,10 +272,9 @@ class World(object):
             return
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
-        _hip.check(fn(d, self.num_envs, self.num_envs, self.pos.data_ptr(), self.vel.data_ptr(),
-                      self.goal.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
-                      self.info.data_ptr() if self.info.numel() else None,
-                      _hip.stream_of(self.device)), 'mpe_observe')
+        b = self._buf
+        b.info = self.info.data_ptr() if self.info.numel() else None
+        _hip.check(fn(d, self.num_envs, self.num_envs, b, _hip.stream_of(self.device)), 'mpe_observe')
         self._gather_tick = self._tick
 
     def enable_stats(self):
@@ -271,10 +304,11 @@ class World(object):
         d = self.descriptor()
         keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_env_step_' + _hip.suffix(self.dtype))
-        _hip.check(fn(d, self.num_envs, self.num_envs, self.act.data_ptr(), nptr, self.pos.data_ptr(),
-                      self.vel.data_ptr(), None, self.goal.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
-                      self.info.data_ptr() if (want_info and self.info.numel()) else None, _hip.ptr(self.stats),
-                      _hip.stream_of(self.device)), 'mpe_env_step')
+        b = self._buf
+        b.act, b.noise = self.act.data_ptr(), nptr
+        b.info = self.info.data_ptr() if (want_info and self.info.numel()) else None
+        b.stats = _hip.ptr(self.stats)
+        _hip.check(fn(d, self.num_envs, self.num_envs, b, _hip.stream_of(self.device)), 'mpe_env_step')
         self._tick += 1
         if want_info:
             self._gather_tick = self._tick
@@ -297,15 +331,21 @@ class World(object):
         for i, e in enumerate(self.entities):
             d.size[i], d.mass[i] = e.size, e.mass
             d.movable[i], d.collide[i] = int(bool(e.movable)), int(bool(e.collide))
+        d.reward_variant = int(getattr(self, 'reward_variant', 0))
+        d.n_target_obs = int(getattr(self, 'n_target_obs', 3))
         for i, a in enumerate(self.agents):
-            if not a.silent:
-                raise NotImplementedError('non-silent agents (comm actions) are outside the HIP hot path')
+            if a.c_noise:
+                raise NotImplementedError('c_noise (core.py:229) is outside the HIP hot path')
             if a.action_callback is not None:
                 raise NotImplementedError('scripted agents (action_callback) are outside the HIP hot path')
             d.accel[i] = 5.0 if a.accel is None else a.accel          # environment.py:193-196
             d.max_speed[i] = -1.0 if a.max_speed is None else a.max_speed
             d.u_noise[i] = a.u_noise if a.u_noise else 0.0            # core.py:147
             d.adversary[i] = int(bool(getattr(a, 'adversary', False)))
+            d.silent[i] = int(bool(a.silent))
+            d.force_id[i], d.forced_id[i] = int(a.force_id), int(a.forced_id)
+            d.advleader[i], d.advsuperleader[i] = int(bool(a.advleader)), int(bool(a.advsuperleader))
+            d.obs_r[i] = a.obs_r
         _hip.check(_hip.lib.mpe_desc_check(d), 'mpe_desc_check')
         self._desc = d
         return d
@@ -329,6 +369,7 @@ class World(object):
         d = self.descriptor()
         keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_world_step_' + _hip.suffix(self.dtype))
-        _hip.check(fn(d, self.num_envs, self.num_envs, self.act.data_ptr(), nptr, self.pos.data_ptr(),
-                      self.vel.data_ptr(), None, _hip.stream_of(self.device)), 'mpe_world_step')
+        b = self._buf
+        b.act, b.noise = self.act.data_ptr(), nptr
+        _hip.check(fn(d, self.num_envs, self.num_envs, b, _hip.stream_of(self.device)), 'mpe_world_step')
         self.mark_dirty()

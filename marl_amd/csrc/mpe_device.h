@@ -31,13 +31,23 @@ struct DevDesc {
   uint32_t adversary[MPE_MAX_AGENTS / 32];
   uint8_t adv_list[MPE_MAX_AGENTS];   // agent indices of the adversaries, ascending
   uint8_t good_list[MPE_MAX_AGENTS];  // agent indices of the good agents, ascending
+  // fork's command hierarchy (core.py:153-194; L1F*/S1L* scenarios)
+  int32_t has_lforce;      // some agent has forced_id >= 0
+  int32_t reward_variant, n_target_obs;
+  int32_t act_row0[MPE_MAX_AGENTS];  // first action row of each agent (5 + dim_c rows if not silent)
+  uint32_t silent[MPE_MAX_AGENTS / 32];
+  uint32_t advleader[MPE_MAX_AGENTS / 32];
+  uint32_t advsuper[MPE_MAX_AGENTS / 32];
+  int8_t force_id[MPE_MAX_AGENTS];
+  int8_t forced_id[MPE_MAX_AGENTS];
+  T obs_r2[MPE_MAX_AGENTS];  // obs_r * obs_r, evaluated in T (L1F2_3Targets_100observe.py:206)
 };
 
 template <typename T>
 struct KParams {
   const T *act, *noise;
   const int32_t *goal;  // per-env goal landmark index (simple_adversary / simple_push), else unused
-  T *pos, *vel, *comm, *obs, *rew, *info;
+  T *pos, *vel, *comm, *lforce, *obs, *rew, *info;
   double *stats;
   int64_t B, ld;
   DevDesc<T> d;
@@ -94,6 +104,11 @@ template <> __device__ __forceinline__ double t_exp<double>(double x) { return e
 template <typename T> __device__ __forceinline__ T t_log1p(T x);
 template <> __device__ __forceinline__ float t_log1p<float>(float x) { return log1pf(x); }
 template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
+// np.linalg.norm of a 2-vector (core.py:185,188) = sqrt(dot(x, x)); the BLAS dot behind it rounds as
+// fma(y, y, x*x) (oracle/mpe_oracle.py:_norm2_blas); f32 mode: plain.
+template <typename T> __device__ __forceinline__ T t_norm2(T x, T y);
+template <> __device__ __forceinline__ float t_norm2<float>(float x, float y) { return __builtin_amdgcn_sqrtf(x * x + y * y); }
+template <> __device__ __forceinline__ double t_norm2<double>(double x, double y) { return sqrt(fma(y, y, x * x)); }
 template <typename T> __device__ __forceinline__ T t_abs(T x);
 template <> __device__ __forceinline__ float t_abs<float>(float x) { return fabsf(x); }
 template <> __device__ __forceinline__ double t_abs<double>(double x) { return fabs(x); }
@@ -167,6 +182,59 @@ __device__ __forceinline__ void integrate_vel_sel(T &vx, T &vy, T Fx, T Fy, T ma
     const bool clamp = sp > max_speed;
     vx = clamp ? cx : vx;
     vy = clamp ? cy : vy;
+  }
+}
+
+// apply_leader_force (core.py:153-194) for agent a of the env in column `col`: every leader whose
+// force_id equals a's forced_id, in agent order.  A super-leader's command is the raw c[0:2] and is
+// only observed (core.py:162-163); a leader's command is argmax(c) (first maximum; dim_c == 3 maps
+// to [0, 5, 6], core.py:169-171): 1-4 axis pushes, 5 / 6 the unit vector towards / away from the
+// leader, added to the physical force and to leader_force (mag = 1, core.py:154,190-192).
+// pos_of(entity, component) returns the pre-step position.
+template <typename T, typename PosFn>
+__device__ __forceinline__ void leader_force(const KParams<T> &p, int a, int64_t col, PosFn pos_of, T &Fx, T &Fy,
+                                             T &lfx, T &lfy) {
+  const DevDesc<T> &d = p.d;
+  lfx = T(0);
+  lfy = T(0);
+  const int want = d.forced_id[a];
+  if (want < 0) return;
+  for (int l = 0; l < d.A; ++l) {
+    if (d.force_id[l] != want) continue;
+    const bool mute = bit(d.silent, l);  // action.c stays zeros(dim_c) (core.py:32-36)
+    const T *c = p.act + (int64_t)(d.act_row0[l] + 5) * p.ld + col;
+    if (bit(d.advsuper, l)) {
+      lfx = mute ? T(0) : ld_stream(c);
+      lfy = mute ? T(0) : ld_stream(c + p.ld);
+      continue;
+    }
+    if (mute) continue;  // argmax(zeros) = 0: no push
+    int cmd = 0;
+    T best = ld_stream(c);
+    for (int k = 1; k < d.dim_c; ++k) {
+      const T v = ld_stream(c + (int64_t)k * p.ld);
+      if (v > best || (v != v && best == best)) {  // np.argmax: first maximum, a NaN wins
+        best = v;
+        cmd = k;
+      }
+    }
+    if (d.dim_c == 3) cmd = cmd == 0 ? 0 : cmd + 4;
+    T fx = T(0), fy = T(0);
+    if (cmd == 1) fx = -T(1);
+    else if (cmd == 2) fx = T(1);
+    else if (cmd == 3) fy = -T(1);
+    else if (cmd == 4) fy = T(1);
+    else if (cmd == 5 || cmd == 6) {
+      T dx = pos_of(l, 0) - pos_of(a, 0), dy = pos_of(l, 1) - pos_of(a, 1);
+      if (cmd == 6) { dx = pos_of(a, 0) - pos_of(l, 0); dy = pos_of(a, 1) - pos_of(l, 1); }
+      const T n = t_norm2<T>(dx, dy);
+      fx = t_div<T>(dx, n);
+      fy = t_div<T>(dy, n);
+    }
+    Fx = Fx + fx;
+    Fy = Fy + fy;
+    lfx = lfx + fx;
+    lfy = lfy + fy;
   }
 }
 

@@ -12,7 +12,8 @@
 
 using namespace mpe;
 
-static_assert(sizeof(KParams<double>) <= 4096, "kernarg segment must stay under 4 KiB");
+// by-value kernarg: 16 KiB launches verified on gfx950 (tools/kernarg_probe.hip)
+static_assert(sizeof(KParams<double>) <= 8192, "kernarg segment must stay under 8 KiB");
 
 // ------------------------------------------------------------------------------------------------
 // descriptor helpers (host)
@@ -25,6 +26,10 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
       if (j != i && !h->adversary[j]) ++good_others;
     return 4 + 2 * L + 2 * (A - 1) + 2 * good_others;
   }
+  if (h->kind == MPE_HIER_PURSUIT) {  // L1F2_3Targets_100observe.py:250-253
+    const int nt = L < h->n_target_obs ? L : h->n_target_obs;
+    return 4 + 4 * (A - 1) + (h->forced_id[i] >= 0 ? 2 : 0) + 2 * nt;
+  }
   if (h->kind == MPE_SIMPLE) return 2 + 2 * L;  // simple.py:50
   if (h->kind == MPE_SIMPLE_ADVERSARY)          // simple_adversary.py:137-140
     return 2 * L + 2 * (A - 1) + (h->adversary[i] ? 0 : 2);
@@ -34,12 +39,20 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
 }
 
 static bool kind_has_roles(int kind) {
-  return kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH;
+  return kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH ||
+         kind == MPE_HIER_PURSUIT;
+}
+static int act_dim_of(const mpe_scenario_desc *h, int i) { return 5 + (h->silent[i] ? 0 : h->dim_c); }
+static bool has_lforce(const mpe_scenario_desc *h) {
+  for (int a = 0; a < h->n_agents; ++a)
+    if (h->forced_id[a] >= 0) return true;
+  return false;
 }
 static bool kind_has_goal(int kind) { return kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH; }
 static int info_width_of(const mpe_scenario_desc *h) {
   switch (h->kind) {
     case MPE_SIMPLE_TAG: return 1;
+    case MPE_HIER_PURSUIT: return 1;  // L1F2_3Targets_100observe.py:136-148
     case MPE_SIMPLE_SPREAD: return 4;
     case MPE_SIMPLE_ADVERSARY: return h->n_landmarks + 1;  // simple_adversary.py:58-67
     default: return 0;                                     // simple.py / simple_push.py: no benchmark_data
@@ -56,7 +69,9 @@ extern "C" const char *mpe_strerror(int code) {
     case MPE_ERR_DESC: return "invalid scenario descriptor";
     case MPE_ERR_BATCH: return "bad batch size or row stride (need B >= 1, ld >= B)";
     case MPE_ERR_ALIGN: return "device pointer not aligned to its element type";
-    case MPE_ERR_UNSUPPORTED: return "unsupported world (movable landmarks / unknown scenario kind)";
+    case MPE_ERR_UNSUPPORTED:
+      return "unsupported world (movable landmarks / unknown scenario kind / comm actions outside the "
+             "command-hierarchy scenarios)";
     case MPE_ERR_ARG: return "bad argument";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
@@ -64,7 +79,7 @@ extern "C" const char *mpe_strerror(int code) {
 
 extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   if (!h) return MPE_ERR_NULL;
-  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_SIMPLE_PUSH) return MPE_ERR_UNSUPPORTED;
+  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_HIER_PURSUIT) return MPE_ERR_UNSUPPORTED;
   if (h->n_agents < 1 || h->n_agents > MPE_MAX_AGENTS) return MPE_ERR_DESC;
   if (h->n_landmarks < 0 || h->n_agents + h->n_landmarks > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
   if (h->dim_c < 0 || h->dim_c > 16) return MPE_ERR_DESC;
@@ -79,6 +94,19 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   for (int a = 0; a < h->n_agents; ++a)
     if (!std::isfinite(h->accel[a]) || std::isnan(h->max_speed[a]) || !std::isfinite(h->u_noise[a]))
       return MPE_ERR_DESC;
+  for (int a = 0; a < h->n_agents; ++a) {
+    if (h->force_id[a] < -1 || h->forced_id[a] < -1) return MPE_ERR_DESC;
+    if (!(h->obs_r[a] >= 0.0) || !std::isfinite(h->obs_r[a])) return MPE_ERR_DESC;
+    // comm entries are consumed by the command hierarchy only; the stock scenarios that observe
+    // other.state.c (simple_spread.py:95) are built silent (simple_spread.py:17)
+    if (!h->silent[a] && h->kind != MPE_HIER_PURSUIT) return MPE_ERR_UNSUPPORTED;
+    // a super-leader's command is c[0:2] (core.py:163)
+    if (h->advsuperleader[a] && h->force_id[a] >= 0 && !h->silent[a] && h->dim_c < 2) return MPE_ERR_DESC;
+  }
+  if (h->kind == MPE_HIER_PURSUIT) {
+    if (h->n_target_obs < 0 || h->n_target_obs > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
+    if (h->reward_variant != 0 && h->reward_variant != 1) return MPE_ERR_DESC;
+  }
   if (h->kind == MPE_SIMPLE && h->n_landmarks < 1) return MPE_ERR_DESC;
   if (kind_has_goal(h->kind)) {  // a goal landmark and at least one good agent must exist
     int goods = 0;
@@ -111,6 +139,27 @@ extern "C" int mpe_obs_total(const mpe_scenario_desc *h) {
   for (int i = 0; i < h->n_agents; ++i) r += obs_dim_of(h, i);
   return r;
 }
+extern "C" int mpe_act_dim(const mpe_scenario_desc *h, int agent) {
+  int rc = mpe_desc_check(h);
+  if (rc) return rc;
+  if (agent < 0 || agent >= h->n_agents) return MPE_ERR_ARG;
+  return act_dim_of(h, agent);
+}
+extern "C" int mpe_act_row0(const mpe_scenario_desc *h, int agent) {
+  int rc = mpe_desc_check(h);
+  if (rc) return rc;
+  if (agent < 0 || agent >= h->n_agents) return MPE_ERR_ARG;
+  int r = 0;
+  for (int i = 0; i < agent; ++i) r += act_dim_of(h, i);
+  return r;
+}
+extern "C" int mpe_act_total(const mpe_scenario_desc *h) {
+  int rc = mpe_desc_check(h);
+  if (rc) return rc;
+  int r = 0;
+  for (int i = 0; i < h->n_agents; ++i) r += act_dim_of(h, i);
+  return r;
+}
 extern "C" int mpe_info_width(const mpe_scenario_desc *h) {
   int rc = mpe_desc_check(h);
   if (rc) return rc;
@@ -136,7 +185,10 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
   d.cforce = (T)h->contact_force;
   d.k = (T)h->contact_margin;
   d.inv_k = (T)(1.0 / h->contact_margin);
-  int row = 0;
+  d.has_lforce = has_lforce(h) ? 1 : 0;
+  d.reward_variant = h->reward_variant;
+  d.n_target_obs = h->n_target_obs;
+  int row = 0, arow = 0;
   for (int e = 0; e < d.E; ++e) {
     d.size[e] = (T)h->size[e];
     if (h->movable[e]) d.movable[e >> 5] |= 1u << (e & 31);
@@ -155,6 +207,14 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     }
     d.obs_row0[a] = row;
     row += obs_dim_of(h, a);
+    d.act_row0[a] = arow;
+    arow += act_dim_of(h, a);
+    if (h->silent[a]) d.silent[a >> 5] |= 1u << (a & 31);
+    if (h->advleader[a]) d.advleader[a >> 5] |= 1u << (a & 31);
+    if (h->advsuperleader[a]) d.advsuper[a >> 5] |= 1u << (a & 31);
+    d.force_id[a] = h->force_id[a];
+    d.forced_id[a] = h->forced_id[a];
+    d.obs_r2[a] = (T)h->obs_r[a] * (T)h->obs_r[a];
   }
   d.obs_total = row;
   int ncol = 0;
@@ -185,6 +245,7 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
     default: return SMALL_NONE;
   }
   for (int a = 0; a < A; ++a) {
+    if (!h->silent[a] || h->forced_id[a] >= 0) return SMALL_NONE;  // fixed [A][5] action rows, no commands
     if (!h->movable[a]) return SMALL_NONE;
     if ((h->max_speed[a] >= 0.0) != has_max) return SMALL_NONE;
     if (h->kind != MPE_SIMPLE_SPREAD && h->kind != MPE_SIMPLE && (h->adversary[a] != 0) != (a < nadv)) return SMALL_NONE;
@@ -289,59 +350,64 @@ static int check_common(const mpe_scenario_desc *h, int64_t B, int64_t ld) {
   return MPE_OK;
 }
 
+// Pointer checks shared by the three stepping entry points; fills the kernel parameters.
 template <typename T>
-static int world_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const T *act, const T *noise,
-                           T *pos, T *vel, T *comm, void *stream) {
+static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const mpe_buffers *b, bool do_step,
+                        bool do_obs, KParams<T> &p) {
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
-  if (!act || !pos || !vel) return MPE_ERR_NULL;
-  if (misaligned<T>(act) || misaligned<T>(noise) || misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm))
+  if (!b || !b->pos || !b->vel) return MPE_ERR_NULL;
+  if (do_step && !b->act) return MPE_ERR_NULL;
+  const bool lf = has_lforce(h);
+  if (lf && !b->lforce) return MPE_ERR_NULL;
+  if (do_obs && kind_has_goal(h->kind) && !b->goal) return MPE_ERR_NULL;
+  p.pos = (T *)b->pos;
+  p.vel = (T *)b->vel;
+  p.lforce = lf ? (T *)b->lforce : nullptr;
+  if (do_step) {
+    p.act = (const T *)b->act;
+    p.noise = (const T *)b->noise;
+    p.comm = (T *)b->comm;
+  }
+  if (do_obs) {
+    p.goal = b->goal;
+    p.obs = (T *)b->obs;
+    p.rew = (T *)b->rew;
+    p.info = info_width_of(h) == 0 ? nullptr : (T *)b->info;  // scenario without benchmark_data
+    p.stats = do_step ? b->stats : nullptr;
+  }
+  if (misaligned<T>(p.act) || misaligned<T>(p.noise) || misaligned<T>(p.pos) || misaligned<T>(p.vel) ||
+      misaligned<T>(p.comm) || misaligned<T>(p.lforce) || misaligned<T>(p.obs) || misaligned<T>(p.rew) ||
+      misaligned<T>(p.info) || misaligned<double>(p.stats) || misaligned<int32_t>(p.goal))
     return MPE_ERR_ALIGN;
-  KParams<T> p{};
-  p.act = act; p.noise = noise; p.pos = pos; p.vel = vel; p.comm = comm;
-  p.B = B; p.ld = ld;
+  p.B = B;
+  p.ld = ld;
   to_device_desc<T>(h, p.d);
+  return MPE_OK;
+}
+
+template <typename T>
+static int world_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const mpe_buffers *b, void *stream) {
+  KParams<T> p{};
+  int rc = bind_buffers<T>(h, B, ld, b, true, false, p);
+  if (rc) return rc;
   return launch<T, true, false>(h, p, (hipStream_t)stream);
 }
 
 template <typename T>
-static int observe_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const T *pos, const T *vel,
-                        const int32_t *goal, T *obs, T *rew, T *info, void *stream) {
-  int rc = check_common<T>(h, B, ld);
-  if (rc) return rc;
-  if (!pos || !vel) return MPE_ERR_NULL;
-  if (info_width_of(h) == 0) info = nullptr;  // scenario has no benchmark_data
-  if (!obs && !rew && !info) return MPE_ERR_NULL;
-  if (kind_has_goal(h->kind) && !goal) return MPE_ERR_NULL;
-  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(obs) || misaligned<T>(rew) ||
-      misaligned<T>(info) || misaligned<int32_t>(goal))
-    return MPE_ERR_ALIGN;
+static int observe_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const mpe_buffers *b, void *stream) {
   KParams<T> p{};
-  p.pos = const_cast<T *>(pos); p.vel = const_cast<T *>(vel); p.goal = goal;
-  p.obs = obs; p.rew = rew; p.info = info;
-  p.B = B; p.ld = ld;
-  to_device_desc<T>(h, p.d);
+  int rc = bind_buffers<T>(h, B, ld, b, false, true, p);
+  if (rc) return rc;
+  if (!p.obs && !p.rew && !p.info) return MPE_ERR_NULL;
   return launch<T, false, true>(h, p, (hipStream_t)stream);
 }
 
 template <typename T>
-static int env_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const T *act, const T *noise, T *pos,
-                         T *vel, T *comm, const int32_t *goal, T *obs, T *rew, T *info, double *stats,
-                         void *stream) {
-  int rc = check_common<T>(h, B, ld);
-  if (rc) return rc;
-  if (!act || !pos || !vel) return MPE_ERR_NULL;
-  if (kind_has_goal(h->kind) && !goal) return MPE_ERR_NULL;
-  if (info_width_of(h) == 0) info = nullptr;  // scenario has no benchmark_data
-  if (misaligned<T>(act) || misaligned<T>(noise) || misaligned<T>(pos) || misaligned<T>(vel) ||
-      misaligned<T>(comm) || misaligned<T>(obs) || misaligned<T>(rew) || misaligned<T>(info) ||
-      misaligned<double>(stats) || misaligned<int32_t>(goal))
-    return MPE_ERR_ALIGN;
+static int env_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const mpe_buffers *b, void *stream) {
   KParams<T> p{};
-  p.act = act; p.noise = noise; p.pos = pos; p.vel = vel; p.comm = comm; p.goal = goal;
-  p.obs = obs; p.rew = rew; p.info = info; p.stats = stats;
-  p.B = B; p.ld = ld;
-  to_device_desc<T>(h, p.d);
+  int rc = bind_buffers<T>(h, B, ld, b, true, true, p);
+  if (rc) return rc;
   return launch<T, true, true>(h, p, (hipStream_t)stream);
 }
 
@@ -376,11 +442,12 @@ __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E
 
 template <typename T>
 static int reset_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_t seed, uint32_t episode,
-                      uint64_t env_id0, const uint8_t *mask, T *pos, T *vel, T *comm, int32_t *goal,
-                      void *stream) {
+                      uint64_t env_id0, const uint8_t *mask, const mpe_buffers *b, void *stream) {
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
-  if (!pos || !vel) return MPE_ERR_NULL;
+  if (!b || !b->pos || !b->vel) return MPE_ERR_NULL;
+  T *pos = (T *)b->pos, *vel = (T *)b->vel, *comm = (T *)b->comm;
+  int32_t *goal = b->goal;
   if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm) || misaligned<int32_t>(goal))
     return MPE_ERR_ALIGN;
   if (h->n_landmarks < 1) goal = nullptr;
@@ -420,24 +487,22 @@ extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, do
 // exported typed entry points
 // ------------------------------------------------------------------------------------------------
 #define MPE_EXPORT_TYPED(SUF, T)                                                                               \
-  extern "C" int mpe_world_step_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const T *act,         \
-                                      const T *noise, T *pos, T *vel, T *comm, void *stream) {                 \
-    return world_step_impl<T>(d, B, ld, act, noise, pos, vel, comm, stream);                                   \
+  extern "C" int mpe_world_step_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const mpe_buffers *b, \
+                                      void *stream) {                                                          \
+    return world_step_impl<T>(d, B, ld, b, stream);                                                            \
   }                                                                                                            \
-  extern "C" int mpe_observe_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const T *pos,            \
-                                   const T *vel, const int32_t *goal, T *obs, T *rew, T *info,                 \
+  extern "C" int mpe_observe_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const mpe_buffers *b,    \
                                    void *stream) {                                                             \
-    return observe_impl<T>(d, B, ld, pos, vel, goal, obs, rew, info, stream);                                  \
+    return observe_impl<T>(d, B, ld, b, stream);                                                               \
   }                                                                                                            \
-  extern "C" int mpe_env_step_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const T *act,           \
-                                    const T *noise, T *pos, T *vel, T *comm, const int32_t *goal, T *obs,      \
-                                    T *rew, T *info, double *stats, void *stream) {                            \
-    return env_step_impl<T>(d, B, ld, act, noise, pos, vel, comm, goal, obs, rew, info, stats, stream);        \
+  extern "C" int mpe_env_step_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const mpe_buffers *b,   \
+                                    void *stream) {                                                            \
+    return env_step_impl<T>(d, B, ld, b, stream);                                                              \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
-                                 uint32_t episode, uint64_t env_id0, const uint8_t *mask, T *pos, T *vel,      \
-                                 T *comm, int32_t *goal, void *stream) {                                       \
-    return reset_impl<T>(d, B, ld, seed, episode, env_id0, mask, pos, vel, comm, goal, stream);                \
+                                 uint32_t episode, uint64_t env_id0, const uint8_t *mask,                      \
+                                 const mpe_buffers *b, void *stream) {                                         \
+    return reset_impl<T>(d, B, ld, seed, episode, env_id0, mask, b, stream);                                   \
   }
 
 MPE_EXPORT_TYPED(f32, float)

@@ -5,8 +5,9 @@
 //   coalesced 256-byte row segment of the SoA arrays), chunk <-> subset of agents (a % NCH).
 //   TILE = 64 for f32 (chunk = one wavefront), 32 for f64 (chunk = half a wavefront).
 //
-//   LDS:  sPos[2E][TILE]  sVel[max(2A, aux)][TILE]   (the reward scratch sAux aliases sVel once the
-//         observations, the last reader of sVel, are out: E=96/A=64 is exactly 80 KiB = 2 blocks/CU)
+//   LDS:  sPos[2E][TILE]  (sLf[2A][TILE] leader_force, command hierarchies only)  sVel[max(2A, aux)][TILE]
+//         (the reward scratch sAux aliases sVel once the observations, the last reader of sVel, are
+//         out: E=96/A=64 is exactly 80 KiB = 2 blocks/CU)
 //
 //   phase 0  cooperative load of pos rows -> sPos
 //   phase 1  per (env, agent a): decode action, add u_noise, sum the one-sided contact forces over
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   const DevDesc<T> &d = p.d;
   const int A = d.A, L = d.L, E = d.E;
   T *sPos = reinterpret_cast<T *>(smem_raw);
-  T *sVel = sPos + 2 * E * TILE;
+  T *sLf = sPos + 2 * E * TILE;
+  T *sVel = sLf + (d.has_lforce ? 2 * A * TILE : 0);
   T *sAux = sVel;  // valid only after the observation phase
 
   const int lane = threadIdx.x % TILE;
@@ -45,8 +47,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
 
     // ---- phase 0 ------------------------------------------------------------------------------
     for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = p.pos[(int64_t)r * ld + ge];
-    if (!DO_STEP)
+    if (!DO_STEP) {
       for (int r = chunk; r < 2 * A; r += NCH) sVel[r * TILE + lane] = p.vel[(int64_t)r * ld + ge];
+      if (d.has_lforce)
+        for (int r = chunk; r < 2 * A; r += NCH) sLf[r * TILE + lane] = p.lforce[(int64_t)r * ld + ge];
+    }
     __syncthreads();
 
     if (DO_STEP) {
@@ -56,13 +61,24 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         T vy = p.vel[(int64_t)(2 * a + 1) * ld + ge];
         if (bit(d.movable, a)) {
           // environment.py:188-196
-          const T *ar = p.act + (int64_t)(5 * a) * ld + ge;
+          const T *ar = p.act + (int64_t)d.act_row0[a] * ld + ge;
           T Fx = (ar[1 * ld] - ar[2 * ld]) * d.accel[a];
           T Fy = (ar[3 * ld] - ar[4 * ld]) * d.accel[a];
           // core.py:147-148
           if (p.noise != nullptr && d.u_noise[a] != T(0)) {
             Fx = Fx + p.noise[(int64_t)(2 * a) * ld + ge] * d.u_noise[a];
             Fy = Fy + p.noise[(int64_t)(2 * a + 1) * ld + ge] * d.u_noise[a];
+          }
+          // core.py:153-194
+          if (d.has_lforce) {
+            T lfx, lfy;
+            leader_force<T>(p, a, ge, [&](int e, int c) { return sPos[(2 * e + c) * TILE + lane]; }, Fx, Fy, lfx, lfy);
+            sLf[(2 * a) * TILE + lane] = lfx;
+            sLf[(2 * a + 1) * TILE + lane] = lfy;
+            if (active) {
+              p.lforce[(int64_t)(2 * a) * ld + env] = lfx;
+              p.lforce[(int64_t)(2 * a + 1) * ld + env] = lfy;
+            }
           }
           // core.py:199-205
           if (bit(d.collide, a)) {
@@ -129,8 +145,12 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             if (active) p.pos[(int64_t)r * ld + env] = np_;
           }
         }
-        if (p.comm != nullptr && active)
-          for (int c = 0; c < d.dim_c; ++c) p.comm[(int64_t)(a * d.dim_c + c) * ld + env] = T(0);
+        if (p.comm != nullptr && active) {  // core.py:226-230 (c_noise is rejected on the host)
+          const bool mute = bit(d.silent, a);
+          for (int c = 0; c < d.dim_c; ++c)
+            p.comm[(int64_t)(a * d.dim_c + c) * ld + env] =
+                mute ? T(0) : ld_stream(p.act + (int64_t)(d.act_row0[a] + 5 + c) * ld + env);
+        }
       }
       __syncthreads();
     }
@@ -158,6 +178,64 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+          if (d.kind == MPE_HIER_PURSUIT) {
+            // L1F2_3Targets_100observe.py:198-253 (same text in every L1F*/S1L* file)
+            st_stream(o, sVel[(2 * i) * TILE + lane]);
+            st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+            st_stream(o + 2 * ld, pix);
+            st_stream(o + 3 * ld, piy);
+            o += 4 * ld;
+            const T r2 = d.obs_r2[i];
+            const int fi = d.force_id[i], fdi = d.forced_id[i];
+            uint64_t vis = 0;  // others inside the radius or on the same command link (:209-216)
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              const T dx = sPos[(2 * j) * TILE + lane] - pix, dy = sPos[(2 * j + 1) * TILE + lane] - piy;
+              const bool linked = (fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]);
+              const bool v = linked || (dx * dx + dy * dy < r2);
+              vis |= (uint64_t)v << j;
+              st_stream(o, v ? dx : T(0));
+              st_stream(o + ld, v ? dy : T(0));
+              o += 2 * ld;
+            }
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              const bool v = (vis >> j) & 1;
+              st_stream(o, v ? sVel[(2 * j) * TILE + lane] : T(0));
+              st_stream(o + ld, v ? sVel[(2 * j + 1) * TILE + lane] : T(0));
+              o += 2 * ld;
+            }
+            if (fdi >= 0) {  // comm = [agent.leader_force] (:244-246)
+              st_stream(o, sLf[(2 * i) * TILE + lane]);
+              st_stream(o + ld, sLf[(2 * i + 1) * TILE + lane]);
+              o += 2 * ld;
+            }
+            // visible targets, nearest first (stable sort by squared distance, :224-236), then zeros:
+            // one selection pass per output slot over the (sq_dis, index) order.
+            const int nt = L < d.n_target_obs ? L : d.n_target_obs;
+            T prev_d = T(0);
+            int prev_l = -1;
+            bool more = true;
+            for (int k = 0; k < nt; ++k) {
+              int best_l = -1;
+              T best_d = T(0), bx = T(0), by = T(0);
+              if (more) {
+                for (int l = 0; l < L; ++l) {
+                  const T dx = sPos[(2 * (A + l)) * TILE + lane] - pix, dy = sPos[(2 * (A + l) + 1) * TILE + lane] - piy;
+                  const T d2 = dx * dx + dy * dy;
+                  const bool after = prev_l < 0 || d2 > prev_d || (d2 == prev_d && l > prev_l);
+                  if (d2 < r2 && after && (best_l < 0 || d2 < best_d)) { best_l = l; best_d = d2; bx = dx; by = dy; }
+                }
+                more = best_l >= 0;
+                prev_d = best_d;
+                prev_l = best_l;
+              }
+              st_stream(o, bx);
+              st_stream(o + ld, by);
+              o += 2 * ld;
+            }
+            continue;
+          }
           if (d.kind == MPE_SIMPLE_TAG || d.kind == MPE_SIMPLE_SPREAD) {
             st_stream(o, sVel[(2 * i) * TILE + lane]);
             st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
@@ -271,6 +349,64 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           }
           if (want_stats && chunk == 0) {
             const double s_t = group_sum(active ? (double)total : 0.0, TILE);
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        } else if (d.kind == MPE_HIER_PURSUIT) {
+          // n_o = number of targets agent o touches (is_collision, L1F2_3Targets_100observe.py:150-154)
+          int *sCnt = reinterpret_cast<int *>(sAux);  // [A][TILE]
+          for (int o = chunk; o < A; o += NCH) {
+            const T pox = sPos[(2 * o) * TILE + lane], poy = sPos[(2 * o + 1) * TILE + lane];
+            int n = 0;
+            for (int l = A; l < E; ++l)
+              n += touching<T>(sPos[(2 * l) * TILE + lane] - pox, sPos[(2 * l + 1) * TILE + lane] - poy,
+                               d.size[l] + d.size[o]) ? 1 : 0;
+            sCnt[o * TILE + lane] = n;
+          }
+          __syncthreads();
+          int follower_hits = 0;
+          if (want_stats && chunk == 0)
+            for (int o = 0; o < A; ++o) follower_hits += bit(d.advleader, o) ? 0 : sCnt[o * TILE + lane];
+          for (int i = chunk; i < A; i += NCH) {
+            const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+            const bool lead = bit(d.advleader, i), super = bit(d.advsuper, i);
+            const int fi = d.force_id[i];
+            // every term of the reference's running sum is +10 (or +1): exact in T, order-free
+            int n = 0;
+            T unit = T(10);
+            // variant 0 tests advleader first (:167-180), rewardFixed tests advsuperleader first (:127-150)
+            const bool own = d.reward_variant == 0 ? !lead : (!super && !lead);
+            if (own) {
+              n = sCnt[i * TILE + lane];
+            } else if (d.reward_variant == 0 && super) {
+              for (int o = 0; o < A; ++o) n += bit(d.advleader, o) ? 0 : sCnt[o * TILE + lane];  // :176-180
+            } else if (d.reward_variant == 1 && super) {
+              // S1L2F2_10Targets_wide_rewardFixed.py:127-137: is_observed(target, target) is 0 < obs_r
+              unit = T(1);
+              for (int o = 0; o < A; ++o) n += (d.forced_id[o] == fi && T(0) < d.obs_r2[o]) ? L : 0;
+            } else {
+              for (int o = 0; o < A; ++o) n += d.forced_id[o] == fi ? sCnt[o * TILE + lane] : 0;  // :171-175
+            }
+            T r_i = unit * T(n);
+            r_i = r_i - tag_bound<T>(t_abs<T>(pix));  // :183-193
+            r_i = r_i - tag_bound<T>(t_abs<T>(piy));
+            // benchmark_data (:136-148): touching agents of the other team
+            int c_i = 0;
+            const bool i_adv = bit(d.adversary, i);
+            for (int a = 0; a < A; ++a)
+              if (bit(d.adversary, a) != i_adv)
+                c_i += touching<T>(sPos[(2 * a) * TILE + lane] - pix, sPos[(2 * a + 1) * TILE + lane] - piy,
+                                   d.size[a] + d.size[i]) ? 1 : 0;
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, T(c_i));
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              const double s_c = group_sum(active ? (double)c_i : 0.0, TILE);
+              if (lane == 0) { srow[i] += s_r; srow[A + i] += s_c; }
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_t = group_sum(active ? (double)follower_hits : 0.0, TILE);
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
@@ -391,10 +527,13 @@ inline size_t tile_lds_bytes(const mpe_scenario_desc *h, int threads) {
   const int NCH = threads / TILE;
   const int E = h->n_agents + h->n_landmarks;
   size_t aux = h->kind == MPE_SIMPLE_TAG ? (size_t)(NCH + h->n_agents) * TILE * sizeof(int)
-                                         : (size_t)h->n_landmarks * TILE * sizeof(T);
+                                         : (size_t)h->n_landmarks * TILE * sizeof(T);  // hierarchy: A ints < vel rows
   size_t velb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
   if (velb < aux) velb = aux;
-  return (size_t)(2 * E) * TILE * sizeof(T) + velb;
+  size_t lfb = 0;
+  for (int a = 0; a < h->n_agents; ++a)
+    if (h->forced_id[a] >= 0) lfb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
+  return (size_t)(2 * E) * TILE * sizeof(T) + lfb + velb;
 }
 
 inline int64_t tile_grid(int64_t B, int tile) {

@@ -5,9 +5,12 @@
     obs_n = env.reset()                       # list of n tensors [B, obs_dim_i]
     obs_n, reward_n, done_n, info_n = env.step(action_n)
 
-``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190), one
-tensor ``[B, n, 5]``, or one contiguous tensor ``[n, 5, B]`` (the kernel's SoA layout, used in place).  Policies can write straight into ``env.action_views[i]`` (``[B,5]``
-views of the kernel's SoA action buffer) and pass that list: then step() copies nothing.
+``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190; ``[B, 5 +
+dim_c]`` for a non-silent agent, whose space is MultiDiscrete: 5 physical entries then the dim_c comm
+entries, environment.py:161-168), one tensor ``[B, n, 5]``, or one contiguous tensor ``[n, 5, B]`` /
+``[act_total, B]`` (the kernel's SoA layout, used in place).  Policies can write straight into
+``env.action_views[i]`` (``[B, act_dim_i]`` views of the kernel's SoA action buffer) and pass that
+list: then step() copies nothing.
 Returned tensors are views of buffers that the next step()/reset() overwrites.
 
 When the callbacks are the methods of a built-in scenario (simple_tag / simple_spread) the whole
@@ -59,20 +62,26 @@ class MultiAgentEnv(object):
         self.action_space = []
         self.observation_space = []
         for agent in self.agents:
-            if not agent.movable or not agent.silent:
-                raise NotImplementedError('only movable, silent agents are on the HIP hot path')
-            self.action_space.append(spaces.Discrete(world.dim_p * 2 + 1))
+            if not agent.movable:
+                raise NotImplementedError('only movable agents are on the HIP hot path')
+            u_space = spaces.Discrete(world.dim_p * 2 + 1)
+            if agent.silent:
+                self.action_space.append(u_space)
+            else:                                     # environment.py:61-69
+                self.action_space.append(spaces.MultiDiscrete([[0, u_space.n - 1], [0, world.dim_c - 1]]))
             obs_dim = int(observation_callback(agent, self.world).shape[-1])
             self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf, shape=(obs_dim,), dtype=np.float32))
         self._own_act = world.act
-        self.action_views = [world.act[i].t() for i in range(self.n)]      # [B,5] views, strides (1,B)
+        self._uniform = all(agent.silent for agent in self.agents)          # world.act is [n,5,B]
+        self.action_views = [world.act_rows[r0:r0 + n].t()                  # [B,act_dim] views, strides (1,B)
+                             for r0, n in zip(world.act_row0, world.act_dims)]
         self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=world.device)
         self._empty_info = [{} for _ in range(self.n)]
 
     # -- environment.py:157-208: the decode itself runs inside the kernel ------------------------------
     def _set_actions(self, action_n):
         act = self.world.act
-        if torch.is_tensor(action_n) and action_n.dim() == 3 and action_n.is_contiguous() \
+        if torch.is_tensor(action_n) and action_n.dim() == act.dim() and action_n.is_contiguous() \
                 and tuple(action_n.shape) == tuple(act.shape) and action_n.dtype == act.dtype \
                 and action_n.device == act.device and (self.num_envs, self.n) != (5, 5):
             # SoA fast path: a contiguous [n, 5, B] tensor is the kernel's own layout; adopt it in
@@ -82,8 +91,8 @@ class MultiAgentEnv(object):
         if act.data_ptr() != self._own_act.data_ptr():
             self.world.act = act = self._own_act
         if torch.is_tensor(action_n) and action_n.dim() == 3:
-            if tuple(action_n.shape) != (self.num_envs, self.n, 5):
-                raise ValueError('action tensor must be [num_envs, n, 5]')
+            if not self._uniform or tuple(action_n.shape) != (self.num_envs, self.n, 5):
+                raise ValueError('action tensor must be [num_envs, n, 5] (all agents silent)')
             act.copy_(action_n.permute(1, 2, 0))
             return
         if len(action_n) != self.n:
@@ -94,9 +103,10 @@ class MultiAgentEnv(object):
                     and a.shape == v.shape:
                 continue                                   # already in place
             a = torch.as_tensor(a, dtype=act.dtype, device=act.device)
-            if a.shape[-1] != 5:
-                raise ValueError('each action must have 5 components (Discrete(5) soft one-hot)')
-            v.copy_(a.expand(self.num_envs, 5))
+            if a.shape[-1] != v.shape[1]:
+                raise ValueError('action of agent %d must have %d components (5 physical%s)'
+                                 % (i, v.shape[1], '' if v.shape[1] == 5 else ' + dim_c comm'))
+            v.copy_(a.expand(self.num_envs, v.shape[1]))
 
     def step(self, action_n):
         self.agents = self.world.policy_agents

@@ -37,11 +37,10 @@ class HipScenario(BaseScenario):
         from . import _hip
         d = world.descriptor()
         fn = getattr(_hip.lib, 'mpe_reset_' + _hip.suffix(world.dtype))
+        b = _hip.Buffers(pos=world.pos, vel=world.vel, comm=world.comm if world.comm.numel() else None,
+                         goal=world.goal if world.hip_kind in _hip.GOAL_KINDS else None)
         _hip.check(fn(d, world.num_envs, world.num_envs, world.seed, world.episode, world.env_id0,
-                      _hip.ptr(mask), world.pos.data_ptr(), world.vel.data_ptr(),
-                      world.comm.data_ptr() if world.comm.numel() else None,
-                      world.goal.data_ptr() if world.hip_kind in _hip.GOAL_KINDS else None,
-                      _hip.stream_of(world.device)), 'mpe_reset')
+                      _hip.ptr(mask), b, _hip.stream_of(world.device)), 'mpe_reset')
         world.episode += 1
         world.mark_dirty()
 

@@ -9,6 +9,9 @@ import os.path as osp
 def load(name):
     base = name[:-3] if name.endswith('.py') else name
     if osp.sep not in base and '/' not in base:
+        from . import hierarchy
+        if base in hierarchy.PRESETS:       # the fork's L1F*/S1L* files: one parametric scenario
+            return hierarchy.bound_module(base)
         try:
             return importlib.import_module('marl_amd.scenarios.' + base)
         except ModuleNotFoundError:

@@ -631,7 +631,8 @@ class BatchedOracle:
             for l in range(A):
                 if s.force_id[l] < 0 or s.forced_id[i] != s.force_id[l]:
                     continue
-                c = act[offs[l] + 5:offs[l] + 5 + s.dim_c]
+                # a silent agent's action.c stays zeros(dim_c) (environment.py:80,198-206)
+                c = (np.zeros((s.dim_c, B), T) if s.silent[l] else act[offs[l] + 5:offs[l] + 5 + s.dim_c])
                 if s.advsuperleader[l]:
                     lf[i] = c[0:2]
                     continue

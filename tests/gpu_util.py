@@ -32,43 +32,48 @@ class HipSim:
         self.rew = torch.full((A, self.ld), float('nan'), **z)
         self.info = torch.full((A, spec.info_width, self.ld), float('nan'), **z)
         self.goal = torch.zeros(self.ld, dtype=torch.int32, device='cuda')
+        self.lforce = torch.zeros(A, 2, self.ld, **z) if spec.has_leader_force else None
+        self.comm = torch.full((A, max(spec.dim_c, 1), self.ld), float('nan'), **z)[:, :spec.dim_c]
         self.stream = torch.cuda.current_stream().cuda_stream
 
-    def set_state(self, pos, vel, goal=None):
+    def set_state(self, pos, vel, goal=None, lforce=None):
         self.pos[:, :, :self.B] = dev(pos, self.dtype)
         self.vel[:, :, :self.B] = dev(vel, self.dtype)
         if goal is not None:
             self.goal[:self.B] = torch.as_tensor(np.maximum(np.asarray(goal), 0), dtype=torch.int32).cuda()
+        if lforce is not None:
+            self.lforce[:, :, :self.B] = dev(lforce, self.dtype)
 
     def _p(self, t):
         return None if t is None else t.data_ptr()
 
-    def env_step(self, act, noise=None, stats=None, want_info=True):
+    def buffers(self, **kw):
+        """mpe_buffers with the state members set, plus the given tensors."""
+        return _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
+
+    def env_step(self, act, noise=None, stats=None, want_info=True, comm=None):
         self._act, self._noise = act, noise   # keep alive until the stream has consumed them
-        rc = getattr(lib, 'mpe_env_step_' + self.suf)(
-            self.desc, self.B, self.ld, act.data_ptr(), self._p(noise), self.pos.data_ptr(), self.vel.data_ptr(),
-            None, self.goal.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
-            self.info.data_ptr() if (want_info and self.info.numel()) else None, self._p(stats), self.stream)
+        b = self.buffers(act=act, noise=noise, comm=comm, obs=self.obs, rew=self.rew, stats=stats,
+                         info=self.info if (want_info and self.info.numel()) else None)
+        rc = getattr(lib, 'mpe_env_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def world_step(self, act, noise=None, comm=None):
         self._act, self._noise = act, noise
-        rc = getattr(lib, 'mpe_world_step_' + self.suf)(
-            self.desc, self.B, self.ld, act.data_ptr(), self._p(noise), self.pos.data_ptr(), self.vel.data_ptr(),
-            self._p(comm), self.stream)
+        b = self.buffers(act=act, noise=noise, comm=comm)
+        rc = getattr(lib, 'mpe_world_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def observe(self, obs=True, rew=True, info=True):
-        rc = getattr(lib, 'mpe_observe_' + self.suf)(
-            self.desc, self.B, self.ld, self.pos.data_ptr(), self.vel.data_ptr(), self.goal.data_ptr(),
-            self.obs.data_ptr() if obs else None, self.rew.data_ptr() if rew else None,
-            self.info.data_ptr() if (info and self.info.numel()) else None, self.stream)
+        b = self.buffers(obs=self.obs if obs else None, rew=self.rew if rew else None,
+                         info=self.info if (info and self.info.numel()) else None)
+        rc = getattr(lib, 'mpe_observe_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def reset(self, seed, episode, env_id0=0, mask=None):
-        rc = getattr(lib, 'mpe_reset_' + self.suf)(
-            self.desc, self.B, self.ld, seed, episode, env_id0, self._p(mask), self.pos.data_ptr(),
-            self.vel.data_ptr(), None, self.goal.data_ptr(), self.stream)
+        b = self.buffers()
+        rc = getattr(lib, 'mpe_reset_' + self.suf)(self.desc, self.B, self.ld, seed, episode, env_id0,
+                                                   self._p(mask), b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
     def host(self):

@@ -17,5 +17,10 @@ def desc_from_spec(spec):
         d.max_speed[a] = -1.0 if spec.max_speed[a] is None else spec.max_speed[a]
         d.u_noise[a] = spec.u_noise[a] if spec.u_noise[a] else 0.0
         d.adversary[a] = int(spec.adversary[a])
+        d.silent[a] = int(spec.silent[a])
+        d.force_id[a], d.forced_id[a] = spec.force_id[a], spec.forced_id[a]
+        d.advleader[a], d.advsuperleader[a] = int(spec.advleader[a]), int(spec.advsuperleader[a])
+        d.obs_r[a] = spec.obs_r[a]
+    d.reward_variant, d.n_target_obs = spec.reward_variant, spec.n_target_obs
     assert _hip.lib.mpe_desc_check(d) == 0
     return d

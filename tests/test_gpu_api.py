@@ -224,3 +224,61 @@ def test_f1_scenarios_episode_loop_matches_oracle(name, spec, dtype, tol):
     if name != 'simple_adversary':
         with pytest.raises(AttributeError):                                   # like the reference
             make_env(name, benchmark=True, num_envs=4)
+
+
+@pytest.mark.parametrize('name', ['L1F2_3Targets_100observe', 'S1L2F2_10Targets_wide', 'S1L2F2_10Targets_wide_rewardFixed',
+                                  'S1L1F1_10Targets_wide'])
+def test_hierarchy_scenarios_episode_loop_matches_oracle(name):
+    """SURVEY 8f row f2 through the public API: make_env by the reference's file name, MultiDiscrete
+    action spaces for the leaders (environment.py:61-69), 25 steps against the oracle (f64)."""
+    from marl_amd import make_env, spaces
+    from marl_amd.scenarios import hierarchy
+    B, T, tol = 256, 25, 1e-9
+    env = make_env(name, benchmark=True, num_envs=B, dtype=torch.float64, seed=8)
+    w = env.world
+    p = hierarchy.PRESETS[name]
+    A = p['n_follower'] + p['n_leader'] + p['n_super']
+    z = p['zoom']
+    spec = O.ScenarioSpec(
+        kind=O.HIER_PURSUIT, n_agents=A, n_landmarks=p['n_landmarks'], adversary=[True] * A,
+        size=[a.size for a in w.agents] + [l.size for l in w.landmarks], accel=[3.0] * A, max_speed=[1.0] * A,
+        collide=[True] * (A + p['n_landmarks']), movable=[True] * A + [False] * p['n_landmarks'], u_noise=[None] * A,
+        mass=[1.0] * (A + p['n_landmarks']), agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=7,
+        silent=[a.silent for a in w.agents], force_id=[a.force_id for a in w.agents],
+        forced_id=[a.forced_id for a in w.agents], advleader=[a.advleader for a in w.agents],
+        advsuperleader=[a.advsuperleader for a in w.agents], obs_r=[a.obs_r for a in w.agents],
+        reward_variant=p['reward_variant'])
+    assert abs(spec.obs_r[0] - 0.2 * z) < 1e-15
+    for sp, a in zip(env.action_space, w.agents):
+        assert sp == (spaces.Discrete(5) if a.silent else spaces.MultiDiscrete([[0, 4], [0, 6]]))
+    assert [s.shape[0] for s in env.observation_space] == spec.obs_dims
+    assert [tuple(v.shape) for v in env.action_views] == [(B, d) for d in spec.act_dims]
+    obs_n = env.reset()
+    ids = np.arange(B, dtype=np.uint64)
+    assert np.array_equal(w.pos.cpu().numpy(), O.reset_positions(spec, 8, w.episode - 1, ids, np.float64))
+    bo = O.BatchedOracle(spec)
+    pos, vel = _np(w.pos), _np(w.vel)
+    obs0, _, _ = bo.observe(pos, vel)
+    for i in range(env.n):
+        assert np.array_equal(_np(obs_n[i]).T, obs0[i])
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for t in range(T):
+        action_n = [torch.softmax(torch.randn(B, d, generator=gen, device='cuda', dtype=torch.float64), -1)
+                    for d in spec.act_dims]
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        act = np.concatenate([_np(a).T for a in action_n], 0)
+        pos, vel, obs, rew, info, lf = bo.env_step(pos, vel, act, return_lforce=True)
+        np.testing.assert_allclose(_np(w.pos), pos, rtol=0, atol=tol)
+        np.testing.assert_allclose(_np(w.lforce), lf, rtol=0, atol=tol)
+        for i, a in enumerate(w.agents):
+            np.testing.assert_allclose(_np(new_obs_n[i]).T, obs[i], rtol=0, atol=tol)
+            np.testing.assert_allclose(_np(a.leader_force).T, lf[i], rtol=0, atol=tol)
+            want_c = 0.0 if a.silent else act[w.act_row0[i] + 5:w.act_row0[i] + 12].T
+            assert np.array_equal(_np(a.state.c), np.broadcast_to(want_c, (B, 7)))       # core.py:226-230
+        np.testing.assert_allclose(np.stack([_np(x) for x in rew_n]), rew, rtol=0, atol=tol)
+        assert np.array_equal(np.stack([_np(x) for x in info_n['n']]), info[:, 0])
+    # the scenario callbacks stand alone too (make_env.py:40-43 wiring)
+    scen = env.reward_callback.__self__
+    assert torch.equal(scen.reward(w.agents[0], w), rew_n[0]) and torch.equal(scen.observation(w.agents[-1], w), new_obs_n[-1])
+    with pytest.raises(ValueError):
+        env.step([torch.zeros(B, 5, device='cuda', dtype=torch.float64)] * env.n)    # leaders need 12 entries

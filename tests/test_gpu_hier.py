@@ -1,0 +1,217 @@
+"""GPU parity for SURVEY 8f row f2: the fork's follower / leader / super-leader pursuit scenarios
+(multiagent/scenarios/L1F*.py, S1L*.py) -- leader force (core.py:153-194), masked and
+distance-sorted observations, hierarchical rewards -- through the C ABI, against the golden vectors
+generated from the reference and against the CPU oracle.
+
+f64: <= 1e-9 per step over free-running 25-step episodes.  f32: <= 1e-4 relative, teacher-forced;
+envs where the float64 reference is within 1e-5 of a visibility / contact / bound() threshold or
+of a tie in the target ordering are excluded from the f32 comparison of the affected outputs.
+"""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tests.gpu_util import HipSim, dev, golden_soa, lib
+
+F64_TOL = 1e-9
+BASES = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
+         'L1F1_10Targets_wide', 'L1F4_3Targets_wide', 'S1L2F2_10Targets_wide',
+         'S1L2F2_10Targets_wide_rewardFixed']
+HIER_CASES = ['h_' + b + suf for b in BASES for suf in ('', '_dense')]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _maxerr(got, want):
+    return float(np.max(np.abs(got - want))) if got.size else 0.0
+
+
+@pytest.mark.parametrize('name', HIER_CASES)
+def test_f64_trajectory_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    spec = O.hier_spec_from_golden(g)
+    S, T = g['act'].shape[:2]
+    sim = HipSim(spec, S, torch.float64)
+    sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'), lforce=golden_soa(g, 'lforce0'))
+    sim.observe(rew=False, info=False)
+    assert _maxerr(sim.host()[2], g['obs0'].T) == 0.0
+    worst = 0.0
+    for t in range(T):
+        act = dev(g['act'][:, t].T, torch.float64)                   # [act_total, S]
+        sim.env_step(act)
+        pos, vel, obs, rew, info = sim.host()
+        lf = sim.lforce.cpu().numpy()
+        errs = (_maxerr(pos, golden_soa(g, 'pos', t)), _maxerr(vel, golden_soa(g, 'vel', t)),
+                _maxerr(lf, golden_soa(g, 'lforce', t)), _maxerr(obs, g['obs'][:, t].T),
+                _maxerr(rew, golden_soa(g, 'rew', t)), _maxerr(info, golden_soa(g, 'info', t)))
+        worst = max(worst, *errs)
+        assert max(errs) <= F64_TOL, (name, t, errs)
+    print('%s worst |err| = %.3e' % (name, worst))
+
+
+def _near_threshold(spec, P, eps=1e-5):
+    """Envs whose float64 state sits within eps of a discrete decision of the gathers."""
+    A, L = spec.n_agents, spec.n_landmarks
+    size = np.asarray(spec.size)
+    dist = np.sqrt(((P[:A, None] - P[None, :]) ** 2).sum(2))            # [A,E,S]
+    near = np.zeros(P.shape[-1], bool)
+    rad = np.asarray(spec.obs_r)[:, None, None]
+    off = ~np.eye(A, A + L, dtype=bool)[..., None]
+    near |= ((np.abs(dist - rad) < eps) & off).any((0, 1))              # visibility radius
+    dmin = (size[:A, None] + size[None, :])[..., None]
+    near |= ((np.abs(dist - dmin) < eps) & off).any((0, 1))             # contacts
+    ax = np.abs(P[:A])
+    near |= (np.abs(ax - 0.9) < eps).any((0, 1)) | (np.abs(ax - 1.0) < eps).any((0, 1))
+    dl = np.sort(dist[:, A:], axis=1)                                   # target ordering ties
+    if L > 1:
+        near |= (np.diff(dl, axis=1) < eps).any((0, 1))
+    return near
+
+
+@pytest.mark.parametrize('name', HIER_CASES)
+def test_f32_teacher_forced_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    spec = O.hier_spec_from_golden(g)
+    S, T = g['act'].shape[:2]
+    sim = HipSim(spec, S, torch.float32)
+    kept = 0.0
+    for t in range(T):
+        p0 = golden_soa(g, 'pos0') if t == 0 else golden_soa(g, 'pos', t - 1)
+        v0 = golden_soa(g, 'vel0') if t == 0 else golden_soa(g, 'vel', t - 1)
+        sim.set_state(p0, v0)
+        sim.env_step(dev(g['act'][:, t].T, torch.float32))
+        pos, vel, obs, rew, info = sim.host()
+        lf = sim.lforce.double().cpu().numpy()
+        np.testing.assert_allclose(pos, golden_soa(g, 'pos', t), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(vel, golden_soa(g, 'vel', t), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(lf, golden_soa(g, 'lforce', t), rtol=1e-4, atol=1e-4)
+        ok = ~_near_threshold(spec, golden_soa(g, 'pos', t))
+        np.testing.assert_allclose(obs[:, ok], g['obs'][:, t].T[:, ok], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(rew[:, ok], golden_soa(g, 'rew', t)[:, ok], rtol=1e-4, atol=2e-4)
+        np.testing.assert_array_equal(info[..., ok], golden_soa(g, 'info', t)[..., ok])
+        kept += ok.mean()
+    assert kept / T > 0.9
+
+
+def _custom_spec():
+    """A world the presets do not build: 3 commands (core.py:169-171 mapping), two leaders commanding
+    the same followers, a silent leader (its c stays zero), a good agent and a leader under the
+    super-leader, non-colliding entities, mixed masses / speed limits."""
+    A, L = 7, 5
+    return O.ScenarioSpec(
+        kind=O.HIER_PURSUIT, n_agents=A, n_landmarks=L, adversary=[True, True, False, True, True, True, True],
+        size=[0.075, 0.06, 0.05, 0.075, 0.075, 0.08, 0.07] + [0.05, 0.07, 0.05, 0.1, 0.05],
+        accel=[3.0, 3.5, 4.0, 3.0, None, 3.0, 3.0], max_speed=[1.0, None, 1.3, 1.0, 1.0, 0.8, 1.0],
+        collide=[True, True, False, True, True, True, True] + [True, True, False, True, True],
+        movable=[True] * A + [False] * L, u_noise=[None] * A,
+        mass=[1.0, 2.0, 1.0, 1.0, 0.5, 1.0, 1.0] + [1.0] * L,
+        agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=3,
+        silent=[True, True, True, False, False, False, True],
+        force_id=[-1, -1, -1, 1, 1, 3, 1], forced_id=[1, 1, 3, 3, -1, -1, -1],
+        advleader=[False, False, False, True, True, True, True],
+        advsuperleader=[False, False, False, False, False, True, False],
+        obs_r=[0.3, 0.25, 0.5, 0.6, 0.4, 0.7, 0.2], reward_variant=0, n_target_obs=3)
+
+
+def _rand_rollout(spec, B, dtype, steps, seed, reward_variant=None):
+    if reward_variant is not None:
+        spec = dataclasses.replace(spec, reward_variant=reward_variant)
+    rng = np.random.RandomState(seed)
+    E, A = spec.n_entities, spec.n_agents
+    pos = rng.uniform(-1.1, 1.1, (E, 2, B))
+    pos[:, :, : B // 2] *= 0.25                                          # dense half: contacts, visible targets
+    vel = rng.uniform(-0.5, 0.5, (A, 2, B))
+    lf0 = rng.uniform(-1, 1, (A, 2, B))
+    acts = rng.rand(steps, sum(spec.act_dims), B)
+    return spec, pos, vel, lf0, acts
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('which', ['custom', 'S1L2F2_10Targets_wide', 'L1F4_3Targets_wide'])
+def test_f64_random_batch_matches_oracle(golden_dir, which, variant):
+    """20 011 envs (ragged last tile) against the batched CPU oracle: every branch of the command
+    decode and of both reward texts."""
+    base = _custom_spec() if which == 'custom' else O.hier_spec_from_golden(_load(golden_dir, 'h_' + which))
+    B, steps = 20011, 4
+    spec, pos, vel, lf0, acts = _rand_rollout(base, B, torch.float64, steps, 7, variant)
+    sim = HipSim(spec, B, torch.float64)
+    sim.set_state(pos, vel, lforce=lf0)
+    bo = O.BatchedOracle(spec)
+    sim.observe()
+    obs, rew, info = bo.observe(pos, vel, lforce=lf0)
+    got = sim.host()
+    assert _maxerr(got[2], np.concatenate(obs, 0)) == 0.0 and _maxerr(got[3], rew) <= F64_TOL
+    for t in range(steps):
+        sim.env_step(dev(acts[t], torch.float64))
+        pos, vel, obs, rew, info, lf = bo.env_step(pos, vel, acts[t], return_lforce=True)
+        gp, gv, go, gr, gi = sim.host()
+        errs = (_maxerr(gp, pos), _maxerr(gv, vel), _maxerr(sim.lforce.cpu().numpy(), lf),
+                _maxerr(go, np.concatenate(obs, 0)), _maxerr(gr, rew), _maxerr(gi, info))
+        assert max(errs) <= F64_TOL, (which, variant, t, errs)
+    assert (rew >= 1).any() and (info > 0).any() if which == 'custom' else (rew >= 1).any()
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+def test_split_entry_points_equal_fused(golden_dir, dtype):
+    """mpe_world_step + mpe_observe == mpe_env_step bit for bit (ld > B); comm = the leaders' own
+    command entries, zero for silent agents (core.py:226-230); padding untouched."""
+    spec = O.hier_spec_from_golden(_load(golden_dir, 'h_S1L2F2_3Targets_100observe'))
+    B, ld = 1000 + 37, 1200
+    _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 3, 3)
+    a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
+    a.set_state(pos, vel, lforce=lf0)
+    b.set_state(pos, vel, lforce=lf0)
+    comm = torch.full((spec.n_agents, spec.dim_c, ld), 7.0, dtype=dtype, device='cuda')
+    rows = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    for t in range(3):
+        act = torch.zeros(sum(spec.act_dims), ld, dtype=dtype, device='cuda')
+        act[:, :B] = dev(acts[t], dtype)
+        a.env_step(act)
+        b.world_step(act, comm=comm)
+        b.observe()
+    for x, y in zip(a.host() + (a.lforce,), b.host() + (b.lforce,)):
+        x, y = (t.cpu().numpy() if torch.is_tensor(t) else t for t in (x, y))
+        assert np.array_equal(x, y, equal_nan=True)
+    for i in range(spec.n_agents):
+        want = 0.0 if spec.silent[i] else act[rows[i] + 5:rows[i] + 5 + spec.dim_c, :B]
+        assert (comm[i, :, :B] == want).all()
+    assert (comm[:, :, B:] == 7).all()
+    for t in (a.obs, a.rew, a.info):
+        assert torch.isnan(t[..., B:]).all()
+    assert (a.pos[..., B:] == 0).all() and (a.vel[..., B:] == 0).all() and (a.lforce[..., B:] == 0).all()
+
+
+def test_stats_rows_accumulate_rewards_and_contacts(golden_dir):
+    spec = O.hier_spec_from_golden(_load(golden_dir, 'h_S1L2F2_10Targets_wide'))
+    B, steps = 5000 + 3, 3
+    _, pos, vel, lf0, acts = _rand_rollout(spec, B, torch.float64, steps, 11)
+    from marl_amd import _hip
+    sim = HipSim(spec, B, torch.float64)
+    sim.set_state(pos, vel, lforce=lf0)
+    A = spec.n_agents
+    rows, width = lib.mpe_stats_rows(sim.desc, B, 8), lib.mpe_stats_width(sim.desc)
+    stats = torch.zeros(rows, width, dtype=torch.float64, device='cuda')
+    want = np.zeros(width)
+    bo = O.BatchedOracle(spec)
+    for t in range(steps):
+        sim.env_step(dev(acts[t], torch.float64), stats=stats)
+        pos, vel, obs, rew, info, lf = bo.env_step(pos, vel, acts[t], return_lforce=True)
+        want[:A] += rew.sum(1)
+        want[A:2 * A] += info[:, 0].sum(1)
+        want[2 * A + 1] += B
+    out = torch.empty(width, dtype=torch.float64, device='cuda')
+    assert lib.mpe_stats_reduce(stats.data_ptr(), rows, width, out.data_ptr(), sim.stream) == 0
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:2 * A], want[:2 * A], rtol=1e-9, atol=1e-6)
+    assert got[2 * A + 1] == want[2 * A + 1] and got[2 * A] >= 0
+    assert _hip.lib.mpe_info_width(sim.desc) == 1

@@ -372,23 +372,19 @@ def test_c_abi_rejects_bad_arguments():
     sim = HipSim(spec, 8, torch.float64)
     act = torch.zeros(4, 5, 8, dtype=torch.float64, device='cuda')
     f = lib.mpe_env_step_f64
-    args = [sim.desc, 8, 8, act.data_ptr(), None, sim.pos.data_ptr(), sim.vel.data_ptr(), None, None,
-            sim.obs.data_ptr(), sim.rew.data_ptr(), sim.info.data_ptr(), None, sim.stream]
-    assert f(*args) == 0
-    bad = list(args); bad[1] = 0
-    assert f(*bad) == -3
-    bad = list(args); bad[2] = 4
-    assert f(*bad) == -3
-    bad = list(args); bad[3] = None
-    assert f(*bad) == -1
-    bad = list(args); bad[5] = sim.pos.data_ptr() + 4
-    assert f(*bad) == -4
+    good = dict(act=act, obs=sim.obs, rew=sim.rew, info=sim.info)
+    assert f(sim.desc, 8, 8, sim.buffers(**good), sim.stream) == 0
+    assert f(sim.desc, 0, 8, sim.buffers(**good), sim.stream) == -3
+    assert f(sim.desc, 8, 4, sim.buffers(**good), sim.stream) == -3
+    assert f(sim.desc, 8, 8, sim.buffers(**dict(good, act=None)), sim.stream) == -1
+    assert f(sim.desc, 8, 8, None, sim.stream) == -1
+    b = sim.buffers(**good)
+    b.pos = sim.pos.data_ptr() + 4
+    assert f(sim.desc, 8, 8, b, sim.stream) == -4
     d = type(sim.desc).from_buffer_copy(sim.desc)
     d.n_agents = 100
-    bad = list(args); bad[0] = d
-    assert f(*bad) == -2
+    assert f(d, 8, 8, sim.buffers(**good), sim.stream) == -2
     d = type(sim.desc).from_buffer_copy(sim.desc)
     d.movable[5] = 1
-    bad = list(args); bad[0] = d
-    assert f(*bad) == -5
+    assert f(d, 8, 8, sim.buffers(**good), sim.stream) == -5
     torch.cuda.synchronize()

@@ -22,11 +22,11 @@ def _declared_functions():
 def test_library_exports_every_declared_symbol():
     from marl_amd import _hip
     names = _declared_functions()
-    assert len(names) >= 18 and 'mpe_env_step_f32' in names and 'mpe_reset_f64' in names
+    assert len(names) >= 21 and 'mpe_env_step_f32' in names and 'mpe_reset_f64' in names
     raw = ctypes.CDLL(_hip._LIB_PATH)
     for n in names:
         assert hasattr(raw, n), 'libmpe_hip.so does not export %s' % n
-    assert _hip.lib.mpe_abi_version() == 2
+    assert _hip.lib.mpe_abi_version() == 3
     assert _hip.lib.mpe_desc_sizeof() == ctypes.sizeof(_hip.ScenarioDesc)
 
 
@@ -35,11 +35,17 @@ def _desc(spec):
     return desc_from_spec(spec)
 
 
+def _hier_spec(name='h_S1L2F2_10Targets_wide'):
+    return O.hier_spec_from_golden(np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz')))
+
+
 @pytest.mark.parametrize('mk', [lambda: O.simple_tag_spec(), lambda: O.simple_spread_spec(),
                                 lambda: O.simple_tag_spec(48, 16, 32), lambda: O.simple_spread_spec(5, 2),
                                 lambda: O.simple_spec(), lambda: O.simple_adversary_spec(),
                                 lambda: O.simple_adversary_spec(5), lambda: O.simple_push_spec(),
-                                lambda: O.simple_push_spec(4, 2, 2)])
+                                lambda: O.simple_push_spec(4, 2, 2), _hier_spec,
+                                lambda: _hier_spec('h_L1F1_10Targets_wide'),
+                                lambda: _hier_spec('h_L1F4_3Targets_wide')])
 def test_observation_geometry_matches_oracle(mk):
     """KAT-3 through the C ABI's host-only geometry functions."""
     from marl_amd import _hip
@@ -52,6 +58,11 @@ def test_observation_geometry_matches_oracle(mk):
     assert _hip.lib.mpe_info_width(d) == spec.info_width
     assert _hip.lib.mpe_stats_width(d) == 2 * spec.n_agents + 2
     assert _hip.lib.mpe_stats_rows(d, 1000, 4) >= 1
+    # action rows: 5 physical entries + dim_c comm entries for non-silent agents (environment.py:42-76)
+    adims = [_hip.lib.mpe_act_dim(d, i) for i in range(spec.n_agents)]
+    assert adims == spec.act_dims
+    assert _hip.lib.mpe_act_total(d) == sum(adims)
+    assert [_hip.lib.mpe_act_row0(d, i) for i in range(spec.n_agents)] == list(np.cumsum([0] + adims[:-1]))
 
 
 def test_descriptor_validation_and_error_codes():
@@ -74,19 +85,37 @@ def test_descriptor_validation_and_error_codes():
     assert lib.mpe_desc_check(bad) == -2
     assert lib.mpe_obs_dim(d, 4) == -6
     # launch entry points: validation happens first, so these return without touching a device
-    assert lib.mpe_env_step_f32(d, 0, 0, 8, None, 8, 8, None, None, None, None, None, None, None) == -3
-    assert lib.mpe_env_step_f32(d, 4, 2, 8, None, 8, 8, None, None, None, None, None, None, None) == -3
-    assert lib.mpe_env_step_f64(d, 4, 4, None, None, 8, 8, None, None, None, None, None, None, None) == -1
-    assert lib.mpe_env_step_f64(d, 4, 4, 8, None, 12, 8, None, None, None, None, None, None, None) == -4
-    assert lib.mpe_world_step_f32(d, 4, 4, 8, None, None, 8, None, None) == -1
-    assert lib.mpe_observe_f32(d, 4, 4, 8, 8, None, None, None, None, None) == -1
-    assert lib.mpe_reset_f32(d, 4, 4, 0, 0, 0, None, None, 8, None, None, None) == -1
+    def buf(**kw):
+        b = _hip.Buffers()
+        for k, v in kw.items():
+            setattr(b, k, v)
+        return b
+    ok = dict(act=8, pos=8, vel=8)
+    assert lib.mpe_env_step_f32(d, 0, 0, buf(**ok), None) == -3
+    assert lib.mpe_env_step_f32(d, 4, 2, buf(**ok), None) == -3
+    assert lib.mpe_env_step_f32(d, 4, 4, None, None) == -1
+    assert lib.mpe_env_step_f64(d, 4, 4, buf(pos=8, vel=8), None) == -1
+    assert lib.mpe_env_step_f64(d, 4, 4, buf(act=8, pos=12, vel=8), None) == -4
+    assert lib.mpe_world_step_f32(d, 4, 4, buf(act=8, vel=8), None) == -1
+    assert lib.mpe_observe_f32(d, 4, 4, buf(pos=8, vel=8), None) == -1
+    assert lib.mpe_reset_f32(d, 4, 4, 0, 0, 0, None, buf(vel=8), None) == -1
     # goal scenarios need the goal pointer; scenarios without benchmark_data ignore `info`
     da = _desc(O.simple_adversary_spec())
-    assert lib.mpe_env_step_f32(da, 4, 4, 8, None, 8, 8, None, None, 8, 8, None, None, None) == -1
-    assert lib.mpe_observe_f64(da, 4, 4, 8, 8, None, 8, None, None, None) == -1
+    assert lib.mpe_env_step_f32(da, 4, 4, buf(obs=8, rew=8, **ok), None) == -1
+    assert lib.mpe_observe_f64(da, 4, 4, buf(pos=8, vel=8, obs=8), None) == -1
     ds = _desc(O.simple_spec())
-    assert lib.mpe_observe_f64(ds, 4, 4, 8, 8, None, None, None, 8, None) == -1     # only info asked: nothing to do
+    assert lib.mpe_observe_f64(ds, 4, 4, buf(pos=8, vel=8, info=8), None) == -1     # only info asked: nothing to do
+    # a command hierarchy needs the leader_force buffer
+    dh = _desc(_hier_spec())
+    assert lib.mpe_world_step_f64(dh, 4, 4, buf(**ok), None) == -1
+    bad = _hip.ScenarioDesc.from_buffer_copy(dh); bad.reward_variant = 2
+    assert lib.mpe_desc_check(bad) == -2
+    bad = _hip.ScenarioDesc.from_buffer_copy(dh); bad.obs_r[0] = -1.0
+    assert lib.mpe_desc_check(bad) == -2
+    bad = _hip.ScenarioDesc.from_buffer_copy(dh); bad.forced_id[0] = -2
+    assert lib.mpe_desc_check(bad) == -2
+    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.silent[0] = 0                  # comm actions: hierarchy only
+    assert lib.mpe_desc_check(bad) == -5
     bad = _hip.ScenarioDesc.from_buffer_copy(da); bad.adversary[1] = 1; bad.adversary[2] = 1
     assert lib.mpe_desc_check(bad) == -2                                            # no good agent
     dp = _desc(O.simple_push_spec())
@@ -112,6 +141,47 @@ def test_spaces_and_scenario_loader():
         assert callable(getattr(tag.Scenario, name))
     with pytest.raises(FileNotFoundError):
         scenarios.load('no_such_scenario.py')
+    md = spaces.MultiDiscrete([[0, 4], [0, 6]])                    # environment.py:69 for a leader
+    assert md.shape == 2 and md.n_entries == 12 and md == spaces.MultiDiscrete([[0, 4], [0, 6]])
+    assert repr(md) == 'MultiDiscrete2'
+
+
+GOLDEN_HIER = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
+               'L1F1_10Targets_wide', 'L1F4_3Targets_wide', 'S1L2F2_10Targets_wide',
+               'S1L2F2_10Targets_wide_rewardFixed']
+
+
+@pytest.mark.parametrize('name', GOLDEN_HIER)
+def test_hierarchy_presets_match_the_reference_worlds(name):
+    """The parametric scenario's preset reproduces the world the reference file builds: compared
+    with the parameters the golden generator read back from the reference's make_world()."""
+    import marl_amd.scenarios as scenarios
+    from marl_amd import _hip
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'h_%s.npz' % name))
+    spec = O.hier_spec_from_golden(g)
+    sc = scenarios.load(name + '.py').Scenario(observation_radius=1.0)
+    sc._finish_world = lambda world: world              # no GPU here: skip allocation
+    world = sc.make_world()
+    d = world.descriptor()
+    want = _desc(spec)
+    assert bytes(d) == bytes(want)
+    assert [a.silent for a in world.agents] == spec.silent
+    assert d.kind == _hip.MPE_HIER_PURSUIT and d.dim_c == 7
+
+
+def test_hierarchy_presets_cover_every_reference_file():
+    from marl_amd.scenarios import hierarchy
+    ref = ['L1F1_10Targets_wide', 'L1F2_10Targets_wide', 'L1F4_3Targets_wide', 'S1L1F1_10Targets_wide',
+           'S1L2F2_10Targets_wide', 'S1L2F2_10Targets_wide_rewardFixed']
+    ref += ['%s_3Targets_%sobserve' % (f, z) for f in ('L1F2', 'S1L2F2') for z in ('075', '090', '095', '100', '105')]
+    assert sorted(hierarchy.PRESETS) == sorted(ref)
+    for name in ref:
+        sc = hierarchy.bound_module(name).Scenario()
+        sc._finish_world = lambda world: world
+        w = sc.make_world()
+        assert w.descriptor().n_agents == sum(hierarchy.PRESETS[name][k] for k in ('n_super', 'n_leader', 'n_follower'))
+    with pytest.raises(TypeError):
+        hierarchy.Scenario(bogus=1)
 
 
 def test_world_requires_a_gpu_and_has_no_cpu_fallback():
