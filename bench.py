@@ -40,17 +40,23 @@ WORKLOADS = {
     'simple_4M_f32': ('simple', {}, 1 << 22, torch.float32),
     'simple_adversary_1M_f32': ('simple_adversary', {}, 1 << 20, torch.float32),
     'simple_push_512k_f32': ('simple_push', {}, 1 << 19, torch.float32),
+    # the fork's command-hierarchy pursuit scenarios (reference file names)
+    'L1F2_3Targets_1M_f32': ('L1F2_3Targets_100observe', {}, 1 << 20, torch.float32),
+    'S1L2F2_10Targets_1M_f32': ('S1L2F2_10Targets_wide', {}, 1 << 20, torch.float32),
+    'S1L2F2_10Targets_1M_f64': ('S1L2F2_10Targets_wide', {}, 1 << 20, torch.float64),
 }
 
 
 def algorithmic_elems(env, with_info=True):
     """compulsory elements moved per env-step:
-    5A act + 2E pos rd + 2A vel rd + 4A pos,vel wr + sum obs_dim + A reward + A*info_w."""
+    act rows (5A, + dim_c per non-silent agent) + 2E pos rd + 2A vel rd + 4A pos,vel wr + sum obs_dim
+    + A reward + A*info_w (+ 2A leader_force wr and the comm rows wr in a command hierarchy)."""
     w = env.world
     A, E = len(w.agents), len(w.entities)
     obs = sum(s.shape[0] for s in env.observation_space)
     info_w = w.info.shape[1] if (with_info and w.info is not None and env.info_callback is not None) else 0
-    return 5 * A + 2 * E + 2 * A + 4 * A + obs + A + A * info_w
+    extra = (2 * A if w.lforce is not None else 0) + sum(w.dim_c for a in w.agents if not a.silent)
+    return sum(w.act_dims) + 2 * E + 2 * A + 4 * A + obs + A + A * info_w + extra
 
 
 def measured_traffic(workload):
@@ -137,8 +143,21 @@ def main():
     env.world.env_id0 = env_id0
     n = env.n
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    pool = [torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1).contiguous()
-            for _ in range(args.action_buffers)]
+
+    def random_actions():
+        """Soft one-hot actions in the kernel's SoA layout: softmax over each agent's 5 physical entries
+        (and, for a non-silent agent, over its dim_c command entries)."""
+        w = env.world
+        if w.act.dim() == 3:
+            return torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1).contiguous()
+        a = torch.empty_like(w.act_rows)
+        for r0, d in zip(w.act_row0, w.act_dims):
+            for lo, hi in ((r0, r0 + 5), (r0 + 5, r0 + d)):
+                if hi > lo:
+                    a[lo:hi] = torch.softmax(torch.randn(hi - lo, B, generator=gen, device=device, dtype=dtype), dim=0)
+        return a
+
+    pool = [random_actions() for _ in range(args.action_buffers)]
     stats = EpisodeStats(env.world)
     stats_total = torch.zeros(2 * n + 2, dtype=torch.float64, device=device)
 

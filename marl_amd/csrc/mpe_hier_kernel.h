@@ -1,0 +1,313 @@
+// Register-resident env-step kernel for the fork's follower / leader / super-leader pursuit worlds
+// (multiagent/scenarios/L1F*.py, S1L*.py) in their stock shapes: one env per lane, the agent /
+// target counts and the number of followers are template constants, so the state (E positions, A
+// velocities, the leaders' command entries) lives in VGPRs and every loop is unrolled.
+//
+//   agents 0..NF-1          followers: silent, 5 action rows each (L1F2_3Targets_100observe.py:36-46)
+//   agents NF..A-1          leaders / super-leader: 5 + 7 action rows each (:48-70, environment.py:61-69)
+//   entities A..A+L-1       targets (landmarks)
+//
+// Stock flags checked on the host (mpe_hip.hip:small_variant): dim_c == 7, n_target_obs == 3, every
+// agent movable with a max_speed, every entity collides, no u_noise.  Who commands whom (force_id /
+// forced_id), the roles, radii and sizes stay run-time values: they are wave-uniform, so the tests on
+// them are scalar branches.  Anything else runs the LDS-tile kernel (same arithmetic, same order:
+// tests/test_gpu_hier.py checks the two bit for bit).
+#pragma once
+#include "mpe_device.h"
+
+namespace mpe {
+
+constexpr int kHierDimC = 7;
+constexpr int kHierTargets = 3;
+
+template <typename T, int A, int L, int NF, int THREADS, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
+  constexpr int E = A + L;
+  constexpr int C = kHierDimC;
+  constexpr int NT = L < kHierTargets ? L : kHierTargets;
+  static_assert(NF >= 0 && NF < A && A <= 6, "followers first, at least one leader; counter packing holds 6 agents");
+  const DevDesc<T> &d = p.d;
+  const int64_t ld = p.ld;
+  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
+  const bool active = blk0 + threadIdx.x < p.B;
+  // tail lanes shadow the last env (loads stay in bounds) and never store
+  const uint32_t lo = active ? threadIdx.x : (uint32_t)(p.B - 1 - blk0);
+  // first action row of agent a (compile-time: followers first)
+  auto arow = [](int a) { return a < NF ? 5 * a : 5 * NF + (5 + C) * (a - NF); };
+
+  const T *gpos = p.pos + blk0, *gvel = p.vel + blk0;
+  T px[E], py[E], vx[A], vy[A], lfx[A], lfy[A];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    px[e] = ld_state(gpos + (int64_t)(2 * e) * ld + lo);
+    py[e] = ld_state(gpos + (int64_t)(2 * e + 1) * ld + lo);
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    vx[a] = ld_state(gvel + (int64_t)(2 * a) * ld + lo);
+    vy[a] = ld_state(gvel + (int64_t)(2 * a + 1) * ld + lo);
+    lfx[a] = lfy[a] = T(0);
+  }
+
+  if (DO_STEP) {
+    const T *gact = p.act + blk0;
+    T a1[A], a2[A], a3[A], a4[A], c[A - NF > 0 ? A - NF : 1][C];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {  // a[0] (the no-op slot) is never read (environment.py:189-190)
+      a1[a] = ld_stream(gact + (int64_t)(arow(a) + 1) * ld + lo);
+      a2[a] = ld_stream(gact + (int64_t)(arow(a) + 2) * ld + lo);
+      a3[a] = ld_stream(gact + (int64_t)(arow(a) + 3) * ld + lo);
+      a4[a] = ld_stream(gact + (int64_t)(arow(a) + 4) * ld + lo);
+    }
+#pragma unroll
+    for (int l = NF; l < A; ++l)
+#pragma unroll
+      for (int k = 0; k < C; ++k) c[l - NF][k] = ld_stream(gact + (int64_t)(arow(l) + 5 + k) * ld + lo);
+
+    T Fx[A], Fy[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {  // environment.py:188-196
+      Fx[a] = (a1[a] - a2[a]) * d.accel[a];
+      Fy[a] = (a3[a] - a4[a]) * d.accel[a];
+    }
+    // core.py:153-194 (same order as mpe_device.h:leader_force): leaders in agent order
+    int cmd[A - NF > 0 ? A - NF : 1];
+#pragma unroll
+    for (int l = NF; l < A; ++l) {  // np.argmax: first maximum, a NaN wins
+      int k_best = 0;
+      T best = c[l - NF][0];
+#pragma unroll
+      for (int k = 1; k < C; ++k) {
+        const T v = c[l - NF][k];
+        const bool take = v > best || (v != v && best == best);
+        best = take ? v : best;
+        k_best = take ? k : k_best;
+      }
+      cmd[l - NF] = k_best;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const int want = d.forced_id[a];
+      if (want < 0) continue;
+#pragma unroll
+      for (int l = NF; l < A; ++l) {  // silent agents command nobody: their c is zero (argmax 0)
+        if (d.force_id[l] != want) continue;
+        if (bit(d.advsuper, l)) {  // observed only (core.py:162-163)
+          lfx[a] = c[l - NF][0];
+          lfy[a] = c[l - NF][1];
+          continue;
+        }
+        const int k = cmd[l - NF];
+        const T dx = px[l] - px[a], dy = py[l] - py[a];
+        const T n = t_norm2<T>(dx, dy);
+        const T ux = t_div<T>(dx, n), uy = t_div<T>(dy, n);  // cmd 6 is exactly the negation
+        T fx = k == 1 ? -T(1) : (k == 2 ? T(1) : T(0));
+        T fy = k == 3 ? -T(1) : (k == 4 ? T(1) : T(0));
+        fx = k == 5 ? ux : (k == 6 ? -ux : fx);
+        fy = k == 5 ? uy : (k == 6 ? -uy : fy);
+        Fx[a] = Fx[a] + fx;
+        Fy[a] = Fy[a] + fy;
+        lfx[a] = lfx[a] + fx;
+        lfy[a] = lfy[a] + fy;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {  // core.py:199-205, b ascending; only a is pushed
+#pragma unroll
+      for (int b = a + 1; b < E; ++b) {
+        T fx, fy;
+        pair_force<T>(px[a] - px[b], py[a] - py[b], d.size[a] + d.size[b], d, fx, fy);
+        Fx[a] = fx + Fx[a];
+        Fy[a] = fy + Fy[a];
+      }
+    }
+    T *spos = p.pos + blk0, *svel = p.vel + blk0, *slf = p.lforce + blk0;
+    T npx[A], npy[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {  // core.py:211-222
+      integrate_vel_sel<T, true>(vx[a], vy[a], Fx[a], Fy[a], d.mass[a], d.damp1, d.dt, d.max_speed[a]);
+      npx[a] = px[a] + vx[a] * d.dt;
+      npy[a] = py[a] + vy[a] * d.dt;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      px[a] = npx[a];
+      py[a] = npy[a];
+      if (active) {
+        st_state(svel + (int64_t)(2 * a) * ld + lo, vx[a]);
+        st_state(svel + (int64_t)(2 * a + 1) * ld + lo, vy[a]);
+        st_state(spos + (int64_t)(2 * a) * ld + lo, px[a]);
+        st_state(spos + (int64_t)(2 * a + 1) * ld + lo, py[a]);
+        if (p.lforce != nullptr) {
+          st_state(slf + (int64_t)(2 * a) * ld + lo, lfx[a]);
+          st_state(slf + (int64_t)(2 * a + 1) * ld + lo, lfy[a]);
+        }
+      }
+    }
+    if (p.comm != nullptr && active) {  // core.py:226-230
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+          (p.comm + blk0 + (int64_t)(a * C + k) * ld)[lo] = a < NF ? T(0) : c[a < NF ? 0 : a - NF][k];
+    }
+  } else if (DO_OBS && p.lforce != nullptr) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      if (d.forced_id[a] < 0) continue;  // only commanded agents observe it
+      lfx[a] = ld_state(p.lforce + blk0 + (int64_t)(2 * a) * ld + lo);
+      lfy[a] = ld_state(p.lforce + blk0 + (int64_t)(2 * a + 1) * ld + lo);
+    }
+  }
+
+  if (DO_OBS) {
+    const bool want_obs = p.obs != nullptr, want_rew = p.rew != nullptr, want_info = p.info != nullptr,
+               want_stats = p.stats != nullptr;
+    int hits[A];  // targets agent o touches (is_collision, L1F2_3Targets_100observe.py:150-154)
+    // ---- observations (:196-253) and the per-agent target contacts, one agent at a time -------------
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      T tdx[L], tdy[L], td2[L];
+      int n = 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        tdx[l] = px[A + l] - px[i];
+        tdy[l] = py[A + l] - py[i];
+        td2[l] = tdx[l] * tdx[l] + tdy[l] * tdy[l];
+        n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;
+      }
+      hits[i] = n;
+      if (!(want_obs && active)) continue;
+      T *o = p.obs + blk0 + (int64_t)d.obs_row0[i] * ld;
+      int r = 0;
+      st_stream(o + (int64_t)(r++) * ld + lo, vx[i]);
+      st_stream(o + (int64_t)(r++) * ld + lo, vy[i]);
+      st_stream(o + (int64_t)(r++) * ld + lo, px[i]);
+      st_stream(o + (int64_t)(r++) * ld + lo, py[i]);
+      const T r2 = d.obs_r2[i];
+      const int fi = d.force_id[i], fdi = d.forced_id[i];
+      bool vis[A];
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        if (j == i) continue;
+        const T dx = px[j] - px[i], dy = py[j] - py[i];
+        const bool linked = (fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]);
+        vis[j] = linked || (dx * dx + dy * dy < r2);
+        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? dx : T(0));
+        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? dy : T(0));
+      }
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        if (j == i) continue;
+        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? vx[j] : T(0));
+        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? vy[j] : T(0));
+      }
+      if (fdi >= 0) {
+        st_stream(o + (int64_t)(r++) * ld + lo, lfx[i]);
+        st_stream(o + (int64_t)(r++) * ld + lo, lfy[i]);
+      }
+      // visible targets, nearest first, ties by index (stable sort, :242-245), then zeros
+      T prev_d = T(0);
+      int prev_l = -1;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        int best_l = -1;
+        T best_d = T(0), bx = T(0), by = T(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          // k == 0: nothing chosen yet.  Later slots: strictly after the previous pick in (d2, index)
+          // order; once a slot finds nothing (best_l = -1 -> prev_l = L) the rest find nothing either.
+          const bool after = k == 0 || td2[l] > prev_d || (td2[l] == prev_d && l > prev_l);
+          const bool take = td2[l] < r2 && after && (best_l < 0 || td2[l] < best_d);
+          best_l = take ? l : best_l;
+          best_d = take ? td2[l] : best_d;
+          bx = take ? tdx[l] : bx;
+          by = take ? tdy[l] : by;
+        }
+        prev_d = best_l < 0 ? r2 : best_d;  // nothing found: no later d2 < r2 can follow
+        prev_l = best_l < 0 ? L : best_l;
+        st_stream(o + (int64_t)(r++) * ld + lo, bx);
+        st_stream(o + (int64_t)(r++) * ld + lo, by);
+      }
+    }
+    // ---- rewards (:164-194 / S1L2F2_10Targets_wide_rewardFixed.py:127-151), benchmark_data (:136-148) --
+    if (want_rew || want_info || want_stats) {
+      T rew[A];
+      int coll[A];
+      int follower_hits = 0;
+#pragma unroll
+      for (int o = 0; o < A; ++o) follower_hits += bit(d.advleader, o) ? 0 : hits[o];
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+        const bool lead = bit(d.advleader, i), super = bit(d.advsuper, i);
+        const int fi = d.force_id[i];
+        const bool own = d.reward_variant == 0 ? !lead : (!super && !lead);
+        int n = 0;
+        T unit = T(10);
+        if (own) {
+          n = hits[i];
+        } else if (d.reward_variant == 0 && super) {
+          n = follower_hits;
+        } else if (d.reward_variant == 1 && super) {
+          unit = T(1);
+#pragma unroll
+          for (int o = 0; o < A; ++o) n += (d.forced_id[o] == fi && T(0) < d.obs_r2[o]) ? L : 0;
+        } else {
+#pragma unroll
+          for (int o = 0; o < A; ++o) n += d.forced_id[o] == fi ? hits[o] : 0;
+        }
+        T r_i = unit * T(n);
+        r_i = r_i - tag_bound_sel<T>(t_abs<T>(px[i]));
+        r_i = r_i - tag_bound_sel<T>(t_abs<T>(py[i]));
+        rew[i] = r_i;
+        int c_i = 0;
+        const bool i_adv = bit(d.adversary, i);
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+          if (bit(d.adversary, a) != i_adv)
+            c_i += touching<T>(px[a] - px[i], py[a] - py[i], d.size[a] + d.size[i]) ? 1 : 0;
+        coll[i] = c_i;
+        if (want_rew && active) st_stream(p.rew + blk0 + (int64_t)i * ld + lo, r_i);
+        if (want_info && active) st_stream(p.info + blk0 + (int64_t)i * ld + lo, T(c_i));
+      }
+      if (want_stats) {
+        constexpr int W = 2 * A + 2;
+        constexpr int NW = THREADS / 64;
+        __shared__ double sred[NW][W];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // contact counters (<= A-1 <= 4 per lane -> <= 256 per wavefront... 9 bits): two words
+        uint32_t pk0 = 0, pk1 = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+          if (i < 3) pk0 |= (uint32_t)coll[i] << (10 * i);
+          else pk1 |= (uint32_t)coll[i] << (10 * (i - 3));
+        }
+        pk0 = wave_sum_u32(active ? pk0 : 0u);
+        if (A > 3) pk1 = wave_sum_u32(active ? pk1 : 0u);
+        const uint32_t fh = wave_sum_u32(active ? (uint32_t)follower_hits : 0u);
+        const double n_active = (double)__builtin_popcountll(__ballot(active));
+        double rsum[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) rsum[i] = group_sum(active ? (double)rew[i] : 0.0, 64);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < A; ++i) {
+            sred[wave][i] = rsum[i];
+            sred[wave][A + i] = (double)(((i < 3 ? pk0 : pk1) >> (10 * (i < 3 ? i : i - 3))) & 0x3FFu);
+          }
+          sred[wave][2 * A] = (double)fh;
+          sred[wave][2 * A + 1] = n_active;
+        }
+        __syncthreads();
+        if (threadIdx.x < W) {
+          double s = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += sred[w][threadIdx.x];
+          p.stats[(int64_t)blockIdx.x * W + threadIdx.x] += s;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mpe

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "mpe_device.h"
+#include "mpe_hier_kernel.h"
 #include "mpe_small_kernel.h"
 #include "mpe_tile_kernel.h"
 
@@ -227,7 +228,40 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
 // ------------------------------------------------------------------------------------------------
 // kernel selection
 // ------------------------------------------------------------------------------------------------
-enum SmallId { SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3, SMALL_SIMPLE_1_1, SMALL_ADVERSARY_3_2, SMALL_PUSH_10_1 };
+enum SmallId {
+  SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3, SMALL_SIMPLE_1_1, SMALL_ADVERSARY_3_2, SMALL_PUSH_10_1,
+  // command-hierarchy worlds, HIER_<agents>_<targets>_<followers> (mpe_hier_kernel.h)
+  HIER_FIRST,
+  HIER_3_3_2 = HIER_FIRST,  // L1F2_3Targets_*
+  HIER_5_3_4,               // L1F4_3Targets_wide
+  HIER_2_10_1,              // L1F1_10Targets_wide
+  HIER_3_10_2,              // L1F2_10Targets_wide
+  HIER_3_10_1,              // S1L1F1_10Targets_wide
+  HIER_5_3_2,               // S1L2F2_3Targets_*
+  HIER_5_10_2,              // S1L2F2_10Targets_wide(_rewardFixed)
+  HIER_LAST = HIER_5_10_2
+};
+
+// Stock shape of a command-hierarchy world (mpe_hier_kernel.h header), or SMALL_NONE.
+static SmallId hier_variant(const mpe_scenario_desc *h) {
+  const int A = h->n_agents, L = h->n_landmarks;
+  if (h->dim_c != kHierDimC || h->n_target_obs != kHierTargets) return SMALL_NONE;
+  int nf = 0;
+  while (nf < A && h->silent[nf]) ++nf;
+  for (int a = 0; a < A; ++a) {
+    if ((h->silent[a] != 0) != (a < nf)) return SMALL_NONE;       // followers (silent) first
+    if (a < nf && h->force_id[a] >= 0) return SMALL_NONE;         // a silent agent commands nobody
+    if (!h->movable[a] || !(h->max_speed[a] >= 0.0) || h->u_noise[a] != 0.0) return SMALL_NONE;
+  }
+  for (int e = 0; e < A + L; ++e)
+    if (!h->collide[e]) return SMALL_NONE;
+  static const struct { int a, l, nf; SmallId id; } shapes[] = {
+      {3, 3, 2, HIER_3_3_2},   {5, 3, 4, HIER_5_3_4},   {2, 10, 1, HIER_2_10_1}, {3, 10, 2, HIER_3_10_2},
+      {3, 10, 1, HIER_3_10_1}, {5, 3, 2, HIER_5_3_2},   {5, 10, 2, HIER_5_10_2}};
+  for (const auto &s : shapes)
+    if (s.a == A && s.l == L && s.nf == nf) return s.id;
+  return SMALL_NONE;
+}
 
 // The register kernel hard-codes the stock shapes and role flags (mpe_small_kernel.h: which
 // entities collide, who has a max_speed, adversaries first); anything else -> tile kernel.
@@ -242,6 +276,7 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
     case MPE_SIMPLE: id = SMALL_SIMPLE_1_1; if (A != 1 || L != 1) return SMALL_NONE; nadv = 0; ecol = 0; has_max = false; break;
     case MPE_SIMPLE_ADVERSARY: id = SMALL_ADVERSARY_3_2; if (A != 3 || L != 2) return SMALL_NONE; nadv = 1; ecol = 0; has_max = false; break;
     case MPE_SIMPLE_PUSH: id = SMALL_PUSH_10_1; if (A != 10 || L != 1) return SMALL_NONE; nadv = 9; ecol = 10; has_max = false; break;
+    case MPE_HIER_PURSUIT: return hier_variant(h);
     default: return SMALL_NONE;
   }
   for (int a = 0; a < A; ++a) {
@@ -266,6 +301,7 @@ static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype
   if (out) *out = sv;
   if (sv == SMALL_NONE) return 0;
   if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
+  if (sv >= HIER_FIRST) return kSmallThreads;
   return small_threads(B, dtype_bytes);
 }
 
@@ -294,8 +330,27 @@ static int launch_small(const KParams<T> &p, bool noise, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <typename T, int A, int L, int NF, bool DO_STEP, bool DO_OBS>
+static int launch_hier(const KParams<T> &p, hipStream_t s) {
+  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+  hipLaunchKernelGGL((hier_kernel<T, A, L, NF, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) {
+  if constexpr (THREADS == kSmallThreads) {
+    switch (sv) {
+      case HIER_3_3_2: return launch_hier<T, 3, 3, 2, DO_STEP, DO_OBS>(p, s);
+      case HIER_5_3_4: return launch_hier<T, 5, 3, 4, DO_STEP, DO_OBS>(p, s);
+      case HIER_2_10_1: return launch_hier<T, 2, 10, 1, DO_STEP, DO_OBS>(p, s);
+      case HIER_3_10_2: return launch_hier<T, 3, 10, 2, DO_STEP, DO_OBS>(p, s);
+      case HIER_3_10_1: return launch_hier<T, 3, 10, 1, DO_STEP, DO_OBS>(p, s);
+      case HIER_5_3_2: return launch_hier<T, 5, 3, 2, DO_STEP, DO_OBS>(p, s);
+      case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
+      default: break;
+    }
+  }
   switch (sv) {
     case SMALL_TAG_3_1_2: return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, THREADS, DO_STEP, DO_OBS>(p, noise, s);
     case SMALL_SPREAD_3_3: return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, THREADS, DO_STEP, DO_OBS>(p, noise, s);

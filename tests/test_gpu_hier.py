@@ -32,12 +32,21 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + '.npz'))
 
 
+@pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
+def force_tile(request):
+    """The stock shapes run the register kernel (mpe_hier_kernel.h) by default; the hook routes them
+    through the generic LDS-tile kernel too."""
+    lib.mpe_debug_force_tile_kernel(request.param)
+    yield request.param
+    lib.mpe_debug_force_tile_kernel(0)
+
+
 def _maxerr(got, want):
     return float(np.max(np.abs(got - want))) if got.size else 0.0
 
 
 @pytest.mark.parametrize('name', HIER_CASES)
-def test_f64_trajectory_matches_reference(golden_dir, name):
+def test_f64_trajectory_matches_reference(golden_dir, name, force_tile):
     g = _load(golden_dir, name)
     spec = O.hier_spec_from_golden(g)
     S, T = g['act'].shape[:2]
@@ -79,7 +88,7 @@ def _near_threshold(spec, P, eps=1e-5):
 
 
 @pytest.mark.parametrize('name', HIER_CASES)
-def test_f32_teacher_forced_matches_reference(golden_dir, name):
+def test_f32_teacher_forced_matches_reference(golden_dir, name, force_tile):
     g = _load(golden_dir, name)
     spec = O.hier_spec_from_golden(g)
     S, T = g['act'].shape[:2]
@@ -138,7 +147,7 @@ def _rand_rollout(spec, B, dtype, steps, seed, reward_variant=None):
 
 @pytest.mark.parametrize('variant', [0, 1])
 @pytest.mark.parametrize('which', ['custom', 'S1L2F2_10Targets_wide', 'L1F4_3Targets_wide'])
-def test_f64_random_batch_matches_oracle(golden_dir, which, variant):
+def test_f64_random_batch_matches_oracle(golden_dir, which, variant, force_tile):
     """20 011 envs (ragged last tile) against the batched CPU oracle: every branch of the command
     decode and of both reward texts."""
     base = _custom_spec() if which == 'custom' else O.hier_spec_from_golden(_load(golden_dir, 'h_' + which))
@@ -162,7 +171,7 @@ def test_f64_random_batch_matches_oracle(golden_dir, which, variant):
 
 
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
-def test_split_entry_points_equal_fused(golden_dir, dtype):
+def test_split_entry_points_equal_fused(golden_dir, dtype, force_tile):
     """mpe_world_step + mpe_observe == mpe_env_step bit for bit (ld > B); comm = the leaders' own
     command entries, zero for silent agents (core.py:226-230); padding untouched."""
     spec = O.hier_spec_from_golden(_load(golden_dir, 'h_S1L2F2_3Targets_100observe'))
@@ -191,7 +200,31 @@ def test_split_entry_points_equal_fused(golden_dir, dtype):
     assert (a.pos[..., B:] == 0).all() and (a.vel[..., B:] == 0).all() and (a.lforce[..., B:] == 0).all()
 
 
-def test_stats_rows_accumulate_rewards_and_contacts(golden_dir):
+@pytest.mark.parametrize('base', BASES)
+def test_register_and_tile_kernels_bit_identical(golden_dir, base):
+    """Both kernels implement the same operation order: every output equal bit for bit, f64 and f32,
+    on states that exercise contacts, visibility and all seven commands."""
+    spec = O.hier_spec_from_golden(_load(golden_dir, 'h_' + base))
+    B = 4096 + 11
+    for dtype in (torch.float64, torch.float32):
+        _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 4, 21)
+        res = []
+        for ft in (0, 1):
+            lib.mpe_debug_force_tile_kernel(ft)
+            sim = HipSim(spec, B, dtype)
+            sim.set_state(pos, vel, lforce=lf0)
+            comm = torch.zeros(spec.n_agents, spec.dim_c, B, dtype=dtype, device='cuda')
+            sim.observe()
+            out = [t.copy() for t in sim.host()]
+            for t in range(4):
+                sim.env_step(dev(acts[t], dtype), comm=comm)
+            res.append(out + list(sim.host()) + [sim.lforce.cpu().numpy(), comm.cpu().numpy()])
+        lib.mpe_debug_force_tile_kernel(0)
+        for x, y in zip(*res):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, force_tile):
     spec = O.hier_spec_from_golden(_load(golden_dir, 'h_S1L2F2_10Targets_wide'))
     B, steps = 5000 + 3, 3
     _, pos, vel, lf0, acts = _rand_rollout(spec, B, torch.float64, steps, 11)
