@@ -93,6 +93,43 @@ __device__ __forceinline__ void st_state(T *p, T v) {
 #endif
 }
 
+// A window on one SoA array for one workgroup of a one-env-per-lane kernel: `base` points at
+// (row 0, the workgroup's first column); element (row r, lane) is base[r * ld + lane].
+//
+// Tail lanes carry the sentinel kNoLane: their loads read column 0 of the window (always a valid env)
+// and their stores are skipped inside st(), so kernel bodies have no `if (active)` blocks of their
+// own.  That matters for register pressure: with the stores of every agent wrapped in conditional
+// blocks, the compiler kept each block's inputs alive across all of them (the 5-agent / 10-target
+// hierarchy kernel needed 256 VGPRs = 1 wave/SIMD; 147 without).
+//
+// Cache policy: actions / noise are read once and observations / rewards / info are written once ->
+// nontemporal; pos / vel are re-read by the next step -> default.  Measured on MI355X with the
+// simple_tag access shape (40 read rows + 86 write rows, 1Mi envs): 4.9 -> 7.3 TB/s
+// (tools/stream_probe.hip).  The same accesses through raw buffer resources (one VGPR offset + one
+// SGPR row offset, no 64-bit VALU address arithmetic) stream at the same rate in the probe but ran
+// 4-6 % slower inside these kernels, so plain global accesses it is.
+constexpr uint32_t kNoLane = 0xFFFFFFFFu;
+
+template <typename T>
+struct Win {
+  T *base;
+  int64_t ld;
+
+  __device__ __forceinline__ Win(const T *base_, int64_t ld_) : base(const_cast<T *>(base_)), ld(ld_) {}
+  __device__ __forceinline__ T ld_state(int row, uint32_t lane) const {
+    return mpe::ld_state(base + (int64_t)row * ld + (lane == kNoLane ? 0u : lane));
+  }
+  __device__ __forceinline__ T ld_stream(int row, uint32_t lane) const {
+    return mpe::ld_stream(base + (int64_t)row * ld + (lane == kNoLane ? 0u : lane));
+  }
+  __device__ __forceinline__ void st_state(int row, uint32_t lane, T v) const {
+    if (lane != kNoLane) mpe::st_state(base + (int64_t)row * ld + lane, v);
+  }
+  __device__ __forceinline__ void st_stream(int row, uint32_t lane, T v) const {
+    if (lane != kNoLane) mpe::st_stream(base + (int64_t)row * ld + lane, v);
+  }
+};
+
 __device__ __forceinline__ bool bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);

@@ -17,11 +17,16 @@
 
 namespace mpe {
 
+// Occupancy cap, see mpe_small_kernel.h (L1F2_3Targets f32: 94.2 us uncapped at 5 waves/SIMD, 84.5 us at 3)
+#ifndef MPE_HIER_ATTR
+#define MPE_HIER_ATTR __attribute__((amdgpu_waves_per_eu(1, 3)))
+#endif
+
 constexpr int kHierDimC = 7;
 constexpr int kHierTargets = 3;
 
 template <typename T, int A, int L, int NF, int THREADS, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
+__global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr int C = kHierDimC;
   constexpr int NT = L < kHierTargets ? L : kHierTargets;
@@ -30,39 +35,37 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
   const int64_t ld = p.ld;
   const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
   const bool active = blk0 + threadIdx.x < p.B;
-  // tail lanes shadow the last env (loads stay in bounds) and never store
-  const uint32_t lo = active ? threadIdx.x : (uint32_t)(p.B - 1 - blk0);
+  const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
   // first action row of agent a (compile-time: followers first)
   auto arow = [](int a) { return a < NF ? 5 * a : 5 * NF + (5 + C) * (a - NF); };
-
-  const T *gpos = p.pos + blk0, *gvel = p.vel + blk0;
+  const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
   T px[E], py[E], vx[A], vy[A], lfx[A], lfy[A];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    px[e] = ld_state(gpos + (int64_t)(2 * e) * ld + lo);
-    py[e] = ld_state(gpos + (int64_t)(2 * e + 1) * ld + lo);
+    px[e] = wpos.ld_state(2 * e, lo);
+    py[e] = wpos.ld_state(2 * e + 1, lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = ld_state(gvel + (int64_t)(2 * a) * ld + lo);
-    vy[a] = ld_state(gvel + (int64_t)(2 * a + 1) * ld + lo);
+    vx[a] = wvel.ld_state(2 * a, lo);
+    vy[a] = wvel.ld_state(2 * a + 1, lo);
     lfx[a] = lfy[a] = T(0);
   }
 
   if (DO_STEP) {
-    const T *gact = p.act + blk0;
+    const Win<T> wact(p.act + blk0, ld);
     T a1[A], a2[A], a3[A], a4[A], c[A - NF > 0 ? A - NF : 1][C];
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // a[0] (the no-op slot) is never read (environment.py:189-190)
-      a1[a] = ld_stream(gact + (int64_t)(arow(a) + 1) * ld + lo);
-      a2[a] = ld_stream(gact + (int64_t)(arow(a) + 2) * ld + lo);
-      a3[a] = ld_stream(gact + (int64_t)(arow(a) + 3) * ld + lo);
-      a4[a] = ld_stream(gact + (int64_t)(arow(a) + 4) * ld + lo);
+      a1[a] = wact.ld_stream(arow(a) + 1, lo);
+      a2[a] = wact.ld_stream(arow(a) + 2, lo);
+      a3[a] = wact.ld_stream(arow(a) + 3, lo);
+      a4[a] = wact.ld_stream(arow(a) + 4, lo);
     }
 #pragma unroll
     for (int l = NF; l < A; ++l)
 #pragma unroll
-      for (int k = 0; k < C; ++k) c[l - NF][k] = ld_stream(gact + (int64_t)(arow(l) + 5 + k) * ld + lo);
+      for (int k = 0; k < C; ++k) c[l - NF][k] = wact.ld_stream(arow(l) + 5 + k, lo);
 
     T Fx[A], Fy[A];
 #pragma unroll
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
         Fy[a] = fy + Fy[a];
       }
     }
-    T *spos = p.pos + blk0, *svel = p.vel + blk0, *slf = p.lforce + blk0;
+    const Win<T> wlf(p.lforce + blk0, ld);
     T npx[A], npy[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:211-222
@@ -133,30 +136,30 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
     for (int a = 0; a < A; ++a) {
       px[a] = npx[a];
       py[a] = npy[a];
-      if (active) {
-        st_state(svel + (int64_t)(2 * a) * ld + lo, vx[a]);
-        st_state(svel + (int64_t)(2 * a + 1) * ld + lo, vy[a]);
-        st_state(spos + (int64_t)(2 * a) * ld + lo, px[a]);
-        st_state(spos + (int64_t)(2 * a + 1) * ld + lo, py[a]);
-        if (p.lforce != nullptr) {
-          st_state(slf + (int64_t)(2 * a) * ld + lo, lfx[a]);
-          st_state(slf + (int64_t)(2 * a + 1) * ld + lo, lfy[a]);
-        }
+      wvel.st_state(2 * a, lo, vx[a]);
+      wvel.st_state(2 * a + 1, lo, vy[a]);
+      wpos.st_state(2 * a, lo, px[a]);
+      wpos.st_state(2 * a + 1, lo, py[a]);
+      if (p.lforce != nullptr) {
+        wlf.st_state(2 * a, lo, lfx[a]);
+        wlf.st_state(2 * a + 1, lo, lfy[a]);
       }
     }
-    if (p.comm != nullptr && active) {  // core.py:226-230
+    if (p.comm != nullptr) {  // core.py:226-230
+      const Win<T> wcomm(p.comm + blk0, ld);
 #pragma unroll
       for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int k = 0; k < C; ++k)
-          (p.comm + blk0 + (int64_t)(a * C + k) * ld)[lo] = a < NF ? T(0) : c[a < NF ? 0 : a - NF][k];
+          wcomm.st_state(a * C + k, lo, a < NF ? T(0) : c[a < NF ? 0 : a - NF][k]);
     }
   } else if (DO_OBS && p.lforce != nullptr) {
+    const Win<T> wlf0(p.lforce + blk0, ld);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       if (d.forced_id[a] < 0) continue;  // only commanded agents observe it
-      lfx[a] = ld_state(p.lforce + blk0 + (int64_t)(2 * a) * ld + lo);
-      lfy[a] = ld_state(p.lforce + blk0 + (int64_t)(2 * a + 1) * ld + lo);
+      lfx[a] = wlf0.ld_state(2 * a, lo);
+      lfy[a] = wlf0.ld_state(2 * a + 1, lo);
     }
   }
 
@@ -177,13 +180,13 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
         n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;
       }
       hits[i] = n;
-      if (!(want_obs && active)) continue;
-      T *o = p.obs + blk0 + (int64_t)d.obs_row0[i] * ld;
+      if (!want_obs) continue;
+      const Win<T> wobs(p.obs + blk0 + (int64_t)d.obs_row0[i] * ld, ld);  // this agent's rows
       int r = 0;
-      st_stream(o + (int64_t)(r++) * ld + lo, vx[i]);
-      st_stream(o + (int64_t)(r++) * ld + lo, vy[i]);
-      st_stream(o + (int64_t)(r++) * ld + lo, px[i]);
-      st_stream(o + (int64_t)(r++) * ld + lo, py[i]);
+      wobs.st_stream(r++, lo, vx[i]);
+      wobs.st_stream(r++, lo, vy[i]);
+      wobs.st_stream(r++, lo, px[i]);
+      wobs.st_stream(r++, lo, py[i]);
       const T r2 = d.obs_r2[i];
       const int fi = d.force_id[i], fdi = d.forced_id[i];
       bool vis[A];
@@ -193,18 +196,18 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
         const T dx = px[j] - px[i], dy = py[j] - py[i];
         const bool linked = (fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]);
         vis[j] = linked || (dx * dx + dy * dy < r2);
-        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? dx : T(0));
-        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? dy : T(0));
+        wobs.st_stream(r++, lo, vis[j] ? dx : T(0));
+        wobs.st_stream(r++, lo, vis[j] ? dy : T(0));
       }
 #pragma unroll
       for (int j = 0; j < A; ++j) {
         if (j == i) continue;
-        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? vx[j] : T(0));
-        st_stream(o + (int64_t)(r++) * ld + lo, vis[j] ? vy[j] : T(0));
+        wobs.st_stream(r++, lo, vis[j] ? vx[j] : T(0));
+        wobs.st_stream(r++, lo, vis[j] ? vy[j] : T(0));
       }
       if (fdi >= 0) {
-        st_stream(o + (int64_t)(r++) * ld + lo, lfx[i]);
-        st_stream(o + (int64_t)(r++) * ld + lo, lfy[i]);
+        wobs.st_stream(r++, lo, lfx[i]);
+        wobs.st_stream(r++, lo, lfy[i]);
       }
       // visible targets, nearest first, ties by index (stable sort, :242-245), then zeros
       T prev_d = T(0);
@@ -226,12 +229,13 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
         }
         prev_d = best_l < 0 ? r2 : best_d;  // nothing found: no later d2 < r2 can follow
         prev_l = best_l < 0 ? L : best_l;
-        st_stream(o + (int64_t)(r++) * ld + lo, bx);
-        st_stream(o + (int64_t)(r++) * ld + lo, by);
+        wobs.st_stream(r++, lo, bx);
+        wobs.st_stream(r++, lo, by);
       }
     }
     // ---- rewards (:164-194 / S1L2F2_10Targets_wide_rewardFixed.py:127-151), benchmark_data (:136-148) --
     if (want_rew || want_info || want_stats) {
+      const Win<T> wrew(p.rew + blk0, ld), winfo(p.info + blk0, ld);
       T rew[A];
       int coll[A];
       int follower_hits = 0;
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(THREADS) void hier_kernel(const KParams<T> p) {
           if (bit(d.adversary, a) != i_adv)
             c_i += touching<T>(px[a] - px[i], py[a] - py[i], d.size[a] + d.size[i]) ? 1 : 0;
         coll[i] = c_i;
-        if (want_rew && active) st_stream(p.rew + blk0 + (int64_t)i * ld + lo, r_i);
-        if (want_info && active) st_stream(p.info + blk0 + (int64_t)i * ld + lo, T(c_i));
+        if (want_rew) wrew.st_stream(i, lo, r_i);
+        if (want_info) winfo.st_stream(i, lo, T(c_i));
       }
       if (want_stats) {
         constexpr int W = 2 * A + 2;

@@ -97,6 +97,8 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
       return MPE_ERR_DESC;
   for (int a = 0; a < h->n_agents; ++a) {
     if (h->force_id[a] < -1 || h->forced_id[a] < -1) return MPE_ERR_DESC;
+    // commands exist in the hierarchy scenarios only (no stock scenario sets force_id / forced_id)
+    if ((h->force_id[a] >= 0 || h->forced_id[a] >= 0) && h->kind != MPE_HIER_PURSUIT) return MPE_ERR_UNSUPPORTED;
     if (!(h->obs_r[a] >= 0.0) || !std::isfinite(h->obs_r[a])) return MPE_ERR_DESC;
     // comm entries are consumed by the command hierarchy only; the stock scenarios that observe
     // other.state.c (simple_spread.py:95) are built silent (simple_spread.py:17)
@@ -309,7 +311,8 @@ template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   constexpr int TILE = tile_envs<T>();
   const size_t lds = tile_lds_bytes<T>(h, THREADS);
-  auto kern = tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS>;
+  auto kern = h->kind == MPE_HIER_PURSUIT ? tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, true>
+                                          : tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, false>;
   if (lds > 64 * 1024) {
     if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -372,9 +375,6 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s
     bool noise = false;
     if (DO_STEP && p.noise != nullptr)
       for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
-    if constexpr (sizeof(T) == 4) {
-      if (threads == kSmallThreadsBig) return launch_small_id<T, kSmallThreadsBig, DO_STEP, DO_OBS>(sv, p, noise, s);
-    }
     return launch_small_id<T, kSmallThreads, DO_STEP, DO_OBS>(sv, p, noise, s);
   }
   // Large worlds are LDS-limited to 1-2 workgroups per CU: give those workgroups more wavefronts so

@@ -23,19 +23,22 @@
 
 namespace mpe {
 
-// Workgroup size: 1024 lanes when the batch fills the chip (each workgroup then streams one
-// contiguous 4 KiB piece of every SoA row: measured +3.5 % over 256 on MI355X, f32), 256 otherwise so
-// that small batches still spread over all CUs.
-constexpr int kSmallThreadsBig = 1024;
+// Occupancy cap.  Measured on MI355X (simple_tag, 1Mi envs, f32, fused step): 93.9 us at the 5
+// waves/SIMD that the kernel's VGPR count allows, 84.8 us capped at 3 and 84.6 us at 2.  Each
+// wavefront streams ~126 SoA rows; fewer resident wavefronts mean fewer DRAM pages open at once.
+// The hierarchy kernel has the same optimum (L1F2_3Targets: 94.2 us uncapped, 84.5 us at 3).
+// (1024-lane workgroups, +3.5 % when uncapped, need 4 waves/SIMD and lose to this: dropped.)
+// simple.py's world moves 20 elements per env step, not 126: it wants every wavefront it can get
+// (5866 GB/s uncapped, 4803 capped at 3).
+constexpr int small_wave_cap(int kind) { return kind == MPE_SIMPLE ? 8 : 3; }
+#ifndef MPE_SMALL_ATTR
+#define MPE_SMALL_ATTR __attribute__((amdgpu_waves_per_eu(1, small_wave_cap(KIND))))
+#endif
 constexpr int kSmallThreads = 256;
-constexpr int64_t kSmallBigBatch = 1 << 19;
-// f64 needs ~164 VGPRs, which a 1024-lane workgroup cannot have without spilling: f32 only.
-inline int small_threads(int64_t B, int dtype_bytes) {
-  return (dtype_bytes == 4 && B >= kSmallBigBatch) ? kSmallThreadsBig : kSmallThreads;
-}
+inline int small_threads(int64_t, int) { return kSmallThreads; }
 
 template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
+__global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr bool TAG = KIND == MPE_SIMPLE_TAG;
   constexpr bool F1 = KIND >= MPE_SIMPLE;  // simple / simple_adversary / simple_push gathers
@@ -47,34 +50,32 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
   const int64_t ld = p.ld;
   const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
   const bool active = blk0 + threadIdx.x < p.B;
-  // tail lanes shadow the last env (loads stay in bounds) and never store
-  const uint32_t lo = active ? threadIdx.x : (uint32_t)(p.B - 1 - blk0);
-
-  const T *gpos = p.pos + blk0, *gvel = p.vel + blk0;
+  const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
+  const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
   T px[E], py[E], vx[A], vy[A];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    px[e] = ld_state(gpos + (int64_t)(2 * e) * ld + lo);
-    py[e] = ld_state(gpos + (int64_t)(2 * e + 1) * ld + lo);
+    px[e] = wpos.ld_state(2 * e, lo);
+    py[e] = wpos.ld_state(2 * e + 1, lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = ld_state(gvel + (int64_t)(2 * a) * ld + lo);
-    vy[a] = ld_state(gvel + (int64_t)(2 * a + 1) * ld + lo);
+    vx[a] = wvel.ld_state(2 * a, lo);
+    vy[a] = wvel.ld_state(2 * a + 1, lo);
   }
 
   if (DO_STEP) {
-    const T *gact = p.act + blk0;
+    const Win<T> wact(p.act + blk0, ld), wnoise(p.noise + blk0, ld);
     T a1[A], a2[A], a3[A], a4[A], nx[A], ny[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // a[0] (the no-op slot) is never read (environment.py:189-190)
-      a1[a] = ld_stream(gact + (int64_t)(5 * a + 1) * ld + lo);
-      a2[a] = ld_stream(gact + (int64_t)(5 * a + 2) * ld + lo);
-      a3[a] = ld_stream(gact + (int64_t)(5 * a + 3) * ld + lo);
-      a4[a] = ld_stream(gact + (int64_t)(5 * a + 4) * ld + lo);
+      a1[a] = wact.ld_stream(5 * a + 1, lo);
+      a2[a] = wact.ld_stream(5 * a + 2, lo);
+      a3[a] = wact.ld_stream(5 * a + 3, lo);
+      a4[a] = wact.ld_stream(5 * a + 4, lo);
       if (HAS_NOISE) {
-        nx[a] = ld_stream(p.noise + blk0 + (int64_t)(2 * a) * ld + lo);
-        ny[a] = ld_stream(p.noise + blk0 + (int64_t)(2 * a + 1) * ld + lo);
+        nx[a] = wnoise.ld_stream(2 * a, lo);
+        ny[a] = wnoise.ld_stream(2 * a + 1, lo);
       }
     }
     T Fx[A], Fy[A];
@@ -97,21 +98,20 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
         Fy[a] = fy + Fy[a];
       }
     }
-    T *spos = p.pos + blk0, *svel = p.vel + blk0;
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:211-222
       integrate_vel_sel<T, TAG>(vx[a], vy[a], Fx[a], Fy[a], d.mass[a], d.damp1, d.dt, d.max_speed[a]);
       px[a] = px[a] + vx[a] * d.dt;
       py[a] = py[a] + vy[a] * d.dt;
-      if (active) {
-        st_state(svel + (int64_t)(2 * a) * ld + lo, vx[a]);
-        st_state(svel + (int64_t)(2 * a + 1) * ld + lo, vy[a]);
-        st_state(spos + (int64_t)(2 * a) * ld + lo, px[a]);
-        st_state(spos + (int64_t)(2 * a + 1) * ld + lo, py[a]);
-      }
+      wvel.st_state(2 * a, lo, vx[a]);
+      wvel.st_state(2 * a + 1, lo, vy[a]);
+      wpos.st_state(2 * a, lo, px[a]);
+      wpos.st_state(2 * a + 1, lo, py[a]);
     }
-    if (p.comm != nullptr && active)  // core.py:226-227
-      for (int r = 0; r < A * d.dim_c; ++r) (p.comm + blk0 + (int64_t)r * ld)[lo] = T(0);
+    if (p.comm != nullptr) {  // core.py:226-227
+      const Win<T> wcomm(p.comm + blk0, ld);
+      for (int r = 0; r < A * d.dim_c; ++r) wcomm.st_state(r, lo, T(0));
+    }
   }
 
   if constexpr (DO_OBS && F1) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
     int goal = 0;
     T gx = px[A], gy = py[A];
     if (HAS_GOAL) {  // agent.goal_a: per-env landmark index
-      goal = p.goal[blk0 + lo];
+      goal = p.goal[blk0 + (active ? threadIdx.x : (uint32_t)(p.B - 1 - blk0))];  // tail lanes: last env
       goal = goal < 0 ? 0 : (goal >= L ? L - 1 : goal);
 #pragma unroll
       for (int l = 1; l < L; ++l) {
@@ -127,48 +127,49 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
         gy = goal == l ? py[A + l] : gy;
       }
     }
-    if (p.obs != nullptr && active) {
+    if (p.obs != nullptr) {
 #pragma unroll
       for (int i = 0; i < A; ++i) {
-        T *o = p.obs + blk0 + (int64_t)d.obs_row0[i] * ld;
+        const Win<T> wobs(p.obs + blk0 + (int64_t)d.obs_row0[i] * ld, ld);  // this agent's rows
         int r = 0;
         if (KIND != MPE_SIMPLE_ADVERSARY) {
-          st_stream(o + (int64_t)(r++) * ld + lo, vx[i]);
-          st_stream(o + (int64_t)(r++) * ld + lo, vy[i]);
+          wobs.st_stream(r++, lo, vx[i]);
+          wobs.st_stream(r++, lo, vy[i]);
         }
         if (HAS_GOAL && i >= NADV) {
-          st_stream(o + (int64_t)(r++) * ld + lo, gx - px[i]);
-          st_stream(o + (int64_t)(r++) * ld + lo, gy - py[i]);
+          wobs.st_stream(r++, lo, gx - px[i]);
+          wobs.st_stream(r++, lo, gy - py[i]);
           if (KIND == MPE_SIMPLE_PUSH) {  // agent.color (simple_push.py:51-56)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-              st_stream(o + (int64_t)(r++) * ld + lo, k == goal + 1 ? T(0.25) + T(0.5) : T(0.25));
+              wobs.st_stream(r++, lo, k == goal + 1 ? T(0.25) + T(0.5) : T(0.25));
           }
         }
 #pragma unroll
         for (int l = A; l < E; ++l) {
-          st_stream(o + (int64_t)(r++) * ld + lo, px[l] - px[i]);
-          st_stream(o + (int64_t)(r++) * ld + lo, py[l] - py[i]);
+          wobs.st_stream(r++, lo, px[l] - px[i]);
+          wobs.st_stream(r++, lo, py[l] - py[i]);
         }
         if (KIND == MPE_SIMPLE_PUSH && i >= NADV) {  // landmark.color (simple_push.py:43-45)
 #pragma unroll
           for (int l = 0; l < L; ++l)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-              st_stream(o + (int64_t)(r++) * ld + lo, k == l + 1 ? T(0.1) + T(0.8) : T(0.1));
+              wobs.st_stream(r++, lo, k == l + 1 ? T(0.1) + T(0.8) : T(0.1));
         }
         if (KIND != MPE_SIMPLE) {
 #pragma unroll
           for (int j = 0; j < A; ++j) {
             if (j == i) continue;
-            st_stream(o + (int64_t)(r++) * ld + lo, px[j] - px[i]);
-            st_stream(o + (int64_t)(r++) * ld + lo, py[j] - py[i]);
+            wobs.st_stream(r++, lo, px[j] - px[i]);
+            wobs.st_stream(r++, lo, py[j] - py[i]);
           }
         }
       }
     }
     const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;
     if (want_rew || want_info || want_stats) {
+      const Win<T> wrew(p.rew + blk0, ld), winfo(p.info + blk0, ld);
       T m = T(0), adv_rew = T(0);
       if (HAS_GOAL) {
 #pragma unroll
@@ -192,15 +193,14 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
           const T dg = t_sqrt<T>(sqdist<T>(px[i], py[i], gx, gy));
           rew[i] = i < NADV ? m - dg : -dg;
         }
-        if (want_rew && active) st_stream(p.rew + blk0 + (int64_t)i * ld + lo, rew[i]);
-        if (KIND == MPE_SIMPLE_ADVERSARY && want_info && active) {  // simple_adversary.py:58-67
-          T *ir = p.info + blk0 + (int64_t)((L + 1) * i) * ld + lo;
+        if (want_rew) wrew.st_stream(i, lo, rew[i]);
+        if (KIND == MPE_SIMPLE_ADVERSARY && want_info) {  // simple_adversary.py:58-67
           const T dgoal = sqdist<T>(px[i], py[i], gx, gy);
 #pragma unroll
           for (int l = 0; l < L; ++l)
-            st_stream(ir + (int64_t)l * ld,
-                      i < NADV ? (l == 0 ? dgoal : T(0)) : sqdist<T>(px[i], py[i], px[A + l], py[A + l]));
-          st_stream(ir + (int64_t)L * ld, i < NADV ? T(0) : dgoal);
+            winfo.st_stream((L + 1) * i + l, lo,
+                            i < NADV ? (l == 0 ? dgoal : T(0)) : sqdist<T>(px[i], py[i], px[A + l], py[A + l]));
+          winfo.st_stream((L + 1) * i + L, lo, i < NADV ? T(0) : dgoal);
         }
       }
       if (want_stats) {
@@ -227,41 +227,42 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
 
   if constexpr (DO_OBS && !F1) {
     // ---- observations (simple_tag.py:131-147 / simple_spread.py:83-99) ---------------------------
-    if (p.obs != nullptr && active) {
+    if (p.obs != nullptr) {
 #pragma unroll
       for (int i = 0; i < A; ++i) {
-        T *o = p.obs + blk0 + (int64_t)d.obs_row0[i] * ld;
+        const Win<T> wobs(p.obs + blk0 + (int64_t)d.obs_row0[i] * ld, ld);  // this agent's rows
         int r = 0;
-        st_stream(o + (int64_t)(r++) * ld + lo, vx[i]);
-        st_stream(o + (int64_t)(r++) * ld + lo, vy[i]);
-        st_stream(o + (int64_t)(r++) * ld + lo, px[i]);
-        st_stream(o + (int64_t)(r++) * ld + lo, py[i]);
+        wobs.st_stream(r++, lo, vx[i]);
+        wobs.st_stream(r++, lo, vy[i]);
+        wobs.st_stream(r++, lo, px[i]);
+        wobs.st_stream(r++, lo, py[i]);
 #pragma unroll
         for (int l = A; l < E; ++l) {
-          st_stream(o + (int64_t)(r++) * ld + lo, px[l] - px[i]);
-          st_stream(o + (int64_t)(r++) * ld + lo, py[l] - py[i]);
+          wobs.st_stream(r++, lo, px[l] - px[i]);
+          wobs.st_stream(r++, lo, py[l] - py[i]);
         }
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
-          st_stream(o + (int64_t)(r++) * ld + lo, px[j] - px[i]);
-          st_stream(o + (int64_t)(r++) * ld + lo, py[j] - py[i]);
+          wobs.st_stream(r++, lo, px[j] - px[i]);
+          wobs.st_stream(r++, lo, py[j] - py[i]);
         }
         if (TAG) {
 #pragma unroll
           for (int j = NADV; j < A; ++j) {
             if (j == i) continue;
-            st_stream(o + (int64_t)(r++) * ld + lo, vx[j]);
-            st_stream(o + (int64_t)(r++) * ld + lo, vy[j]);
+            wobs.st_stream(r++, lo, vx[j]);
+            wobs.st_stream(r++, lo, vy[j]);
           }
         } else {
-          for (int z = 0; z < d.dim_c * (A - 1); ++z) st_stream(o + (int64_t)(r++) * ld + lo, T(0));
+          for (int z = 0; z < d.dim_c * (A - 1); ++z) wobs.st_stream(r++, lo, T(0));
         }
       }
     }
     // ---- reward / info ------------------------------------------------------------------------
     const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;
     if (want_rew || want_info || want_stats) {
+      const Win<T> wrew(p.rew + blk0, ld), winfo(p.info + blk0, ld);
       T rew[A];
       int coll[A];
       int extra = 0;
@@ -288,9 +289,9 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
 #pragma unroll
         for (int a = 0; a < NADV; ++a) rew[a] = T(10) * T(total);  // simple_tag.py:124-128
         extra = total;
-        if (want_info && active) {
+        if (want_info) {
 #pragma unroll
-          for (int i = 0; i < A; ++i) st_stream(p.info + blk0 + (int64_t)i * ld + lo, T(coll[i]));
+          for (int i = 0; i < A; ++i) winfo.st_stream(i, lo, T(coll[i]));
         }
       } else {
         T r0 = T(0), md = T(0);
@@ -320,16 +321,18 @@ __global__ __launch_bounds__(THREADS) void small_kernel(const KParams<T> p) {
           }
           rew[i] = r;
           coll[i] = c;
-          if (want_info && active) {
-            T *ir = p.info + blk0 + (int64_t)(4 * i) * ld + lo;
-            st_stream(ir, r); st_stream(ir + ld, T(c)); st_stream(ir + 2 * ld, md); st_stream(ir + 3 * ld, T(occ));
+          if (want_info) {
+            winfo.st_stream(4 * i, lo, r);
+            winfo.st_stream(4 * i + 1, lo, T(c));
+            winfo.st_stream(4 * i + 2, lo, md);
+            winfo.st_stream(4 * i + 3, lo, T(occ));
           }
         }
         extra = occ;
       }
-      if (want_rew && active) {
+      if (want_rew) {
 #pragma unroll
-        for (int i = 0; i < A; ++i) st_stream(p.rew + blk0 + (int64_t)i * ld + lo, rew[i]);
+        for (int i = 0; i < A; ++i) wrew.st_stream(i, lo, rew[i]);
       }
       // ---- per-workgroup statistics: wavefront reductions, then one row update per block ---------
       // Small integer counters (<= 3 per lane, so <= 192 per wavefront) are packed four to a word

@@ -24,7 +24,10 @@
 
 namespace mpe {
 
-template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS>
+// HIER: the world is a command hierarchy (kind MPE_HIER_PURSUIT; the only kind that may carry
+// force_id / forced_id / comm actions, mpe_hip.hip:mpe_desc_check).  A template flag so that the
+// stock kinds do not pay for its branches in the per-agent loops (scaled simple_tag: 3.80 -> 3.50 ms).
+template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   constexpr int NCH = THREADS / TILE;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -32,7 +35,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   const int A = d.A, L = d.L, E = d.E;
   T *sPos = reinterpret_cast<T *>(smem_raw);
   T *sLf = sPos + 2 * E * TILE;
-  T *sVel = sLf + (d.has_lforce ? 2 * A * TILE : 0);
+  const bool has_lf = HIER && d.has_lforce;
+  T *sVel = sLf + (has_lf ? 2 * A * TILE : 0);
   T *sAux = sVel;  // valid only after the observation phase
 
   const int lane = threadIdx.x % TILE;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
     for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = p.pos[(int64_t)r * ld + ge];
     if (!DO_STEP) {
       for (int r = chunk; r < 2 * A; r += NCH) sVel[r * TILE + lane] = p.vel[(int64_t)r * ld + ge];
-      if (d.has_lforce)
+      if (has_lf)
         for (int r = chunk; r < 2 * A; r += NCH) sLf[r * TILE + lane] = p.lforce[(int64_t)r * ld + ge];
     }
     __syncthreads();
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         T vy = p.vel[(int64_t)(2 * a + 1) * ld + ge];
         if (bit(d.movable, a)) {
           // environment.py:188-196
-          const T *ar = p.act + (int64_t)d.act_row0[a] * ld + ge;
+          const T *ar = p.act + (int64_t)(HIER ? d.act_row0[a] : 5 * a) * ld + ge;
           T Fx = (ar[1 * ld] - ar[2 * ld]) * d.accel[a];
           T Fy = (ar[3 * ld] - ar[4 * ld]) * d.accel[a];
           // core.py:147-148
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             Fy = Fy + p.noise[(int64_t)(2 * a + 1) * ld + ge] * d.u_noise[a];
           }
           // core.py:153-194
-          if (d.has_lforce) {
+          if (has_lf) {
             T lfx, lfy;
             leader_force<T>(p, a, ge, [&](int e, int c) { return sPos[(2 * e + c) * TILE + lane]; }, Fx, Fy, lfx, lfy);
             sLf[(2 * a) * TILE + lane] = lfx;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           }
         }
         if (p.comm != nullptr && active) {  // core.py:226-230 (c_noise is rejected on the host)
-          const bool mute = bit(d.silent, a);
+          const bool mute = !HIER || bit(d.silent, a);
           for (int c = 0; c < d.dim_c; ++c)
             p.comm[(int64_t)(a * d.dim_c + c) * ld + env] =
                 mute ? T(0) : ld_stream(p.act + (int64_t)(d.act_row0[a] + 5 + c) * ld + env);
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
-          if (d.kind == MPE_HIER_PURSUIT) {
+          if (HIER && d.kind == MPE_HIER_PURSUIT) {
             // L1F2_3Targets_100observe.py:198-253 (same text in every L1F*/S1L* file)
             st_stream(o, sVel[(2 * i) * TILE + lane]);
             st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
-        } else if (d.kind == MPE_HIER_PURSUIT) {
+        } else if (HIER && d.kind == MPE_HIER_PURSUIT) {
           // n_o = number of targets agent o touches (is_collision, L1F2_3Targets_100observe.py:150-154)
           int *sCnt = reinterpret_cast<int *>(sAux);  // [A][TILE]
           for (int o = chunk; o < A; o += NCH) {

@@ -43,6 +43,26 @@ __global__ __launch_bounds__(THREADS) void soa_kernel(const float *__restrict__ 
   }
 }
 
+// Same rows through a raw buffer resource (one VGPR lane offset + one SGPR row offset per access)
+template <int NR, int NW, bool NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void soa_buf_kernel(const float *__restrict__ in, float *__restrict__ out, long B) {
+  const long blk0 = (long)blockIdx.x * THREADS;
+  const bool active = blk0 + threadIdx.x < B;
+  const int lo = active ? (int)(threadIdx.x * 4) : -1;
+  __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in + blk0), 0, -1, 0x00020000);
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + blk0, 0, -1, 0x00020000);
+  const unsigned rb = (unsigned)B * 4u;
+  float acc = 0.f;
+  float r[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, lo, (int)(k * rb), 0));
+#pragma unroll
+  for (int k = 0; k < NR; ++k) acc += r[k];
+#pragma unroll
+  for (int k = 0; k < NW; ++k)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc + r[k % NR] * (float)k), ro, lo, (int)(k * rb), NT ? 2 : 0);
+}
+
 __global__ void copy4(const float4 *__restrict__ in, float4 *__restrict__ out, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -85,6 +105,14 @@ static float time_it(F f, int iters = 20) {
   return ms / iters;
 }
 
+template <int NR, int NW, bool NT, int THREADS>
+static void run_buf(const char *name, const float *in, float *out, long B) {
+  dim3 grid((unsigned)((B + THREADS - 1) / THREADS));
+  float ms = time_it([&] { hipLaunchKernelGGL((soa_buf_kernel<NR, NW, NT, THREADS>), grid, dim3(THREADS), 0, 0, in, out, B); });
+  double bytes = (double)(NR + NW) * B * 4;
+  printf("%-34s NR=%3d NW=%3d V=1 NT=%d T=%4d : %8.1f us  %7.1f GB/s\n", name, NR, NW, (int)NT, THREADS, ms * 1e3, bytes / ms / 1e6);
+}
+
 template <int NR, int NW, int V, bool NT, int THREADS>
 static void run(const char *name, const float *in, float *out, long B) {
   const long nthreads = B / V;
@@ -125,6 +153,10 @@ int main() {
   }
   run<40, 86, 1, false, 256>("soa tag-shaped", in, out, B);
   run<40, 86, 1, true, 256>("soa tag-shaped nt", in, out, B);
+  run_buf<40, 86, false, 256>("soa tag-shaped BUFFER", in, out, B);
+  run_buf<40, 86, true, 256>("soa tag-shaped BUFFER nt", in, out, B);
+  run_buf<40, 86, true, 1024>("soa tag-shaped BUFFER nt", in, out, B);
+  run<40, 86, 1, true, 1024>("soa tag-shaped nt T1024", in, out, B);
   run<40, 86, 2, false, 256>("soa tag-shaped x2", in, out, B);
   run<40, 86, 2, true, 256>("soa tag-shaped x2 nt", in, out, B);
   run<40, 86, 4, false, 256>("soa tag-shaped x4", in, out, B);
