@@ -50,12 +50,13 @@ WORKLOADS = {
 def algorithmic_elems(env, with_info=True):
     """compulsory elements moved per env-step:
     act rows (5A, + dim_c per non-silent agent) + 2E pos rd + 2A vel rd + 4A pos,vel wr + sum obs_dim
-    + A reward + A*info_w (+ 2A leader_force wr and the comm rows wr in a command hierarchy)."""
+    + A reward + A*info_w (+ 2A leader_force wr and A*dim_c comm wr in a command hierarchy)."""
     w = env.world
     A, E = len(w.agents), len(w.entities)
     obs = sum(s.shape[0] for s in env.observation_space)
     info_w = w.info.shape[1] if (with_info and w.info is not None and env.info_callback is not None) else 0
-    extra = (2 * A if w.lforce is not None else 0) + sum(w.dim_c for a in w.agents if not a.silent)
+    # agent.state.c of every agent is rewritten each step once any agent speaks (core.py:224-230)
+    extra = (2 * A if w.lforce is not None else 0) + (A * w.dim_c if any(not a.silent for a in w.agents) else 0)
     return sum(w.act_dims) + 2 * E + 2 * A + 4 * A + obs + A + A * info_w + extra
 
 
@@ -66,7 +67,11 @@ def measured_traffic(workload):
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))['kernels']
-    fused = [v for k, v in ks.items() if 'true, true>' in k]
+
+    def is_fused(name):      # template tails: small/hier <..., DO_STEP, DO_OBS>, tile <..., DO_STEP, DO_OBS, HIER>
+        args = name[name.index('<') + 1:name.rindex('>(')].split(', ')
+        return (args[-3:-1] if 'tile_kernel' in name else args[-2:]) == ['true', 'true']
+    fused = [v for k, v in ks.items() if 'mpe::' in k and is_fused(k)]
     return fused[0]['traffic_bytes'] if fused else None
 
 
