@@ -111,6 +111,8 @@ typedef struct mpe_scenario_desc {
   int32_t reward_variant;            /* 0: L1F.. / S1L.. default; 1: S1L2F2_10Targets_wide_rewardFixed */
   int32_t n_target_obs;              /* target_pos[0:n] in the observation (3)                  */
   double obs_r[MPE_MAX_AGENTS];      /* agent.obs_r: observation radius                         */
+  uint8_t advfollower[MPE_MAX_AGENTS]; /* agent.advfollower (L1F2_3Targets_100observe.py:40): the
+                                          agents whose touch respawns a target (mpe_target_move)   */
 } mpe_scenario_desc;
 
 /*
@@ -209,6 +211,23 @@ int mpe_reset_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t
 int mpe_reset_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
                   uint32_t episode, uint64_t env_id0, const uint8_t *mask, const mpe_buffers *buf,
                   void *stream);
+
+/*
+ * target_move(env) of the fork's training loop (experiments/train_and_eval.py:207-222, called after
+ * every env.step, :314,391): every landmark touched by an agent with advfollower set
+ * (dist < size_l + size_a, strict) is respawned at U(-1, 1)^2.  The reference draws np.random.rand();
+ * this build draws Philox4x32-10 with counter (env_id_lo, env_id_hi, move_counter, 0x80000000 |
+ * landmark) and key = seed (same 53-bit uniform as mpe_reset).  Updates buf->pos in place (landmark
+ * rows only); `count` (may be NULL): int32 [ld], the function's return value per env (number of
+ * respawned landmarks).  Observations already returned by the step are not touched, like in the
+ * reference.
+ */
+int mpe_target_move_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
+                        uint32_t move_counter, uint64_t env_id0, const mpe_buffers *buf, int32_t *count,
+                        void *stream);
+int mpe_target_move_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, uint64_t seed,
+                        uint32_t move_counter, uint64_t env_id0, const mpe_buffers *buf, int32_t *count,
+                        void *stream);
 
 /*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,

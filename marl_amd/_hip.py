@@ -45,6 +45,7 @@ class ScenarioDesc(C.Structure):
         ('advleader', C.c_uint8 * MPE_MAX_AGENTS), ('advsuperleader', C.c_uint8 * MPE_MAX_AGENTS),
         ('reward_variant', C.c_int32), ('n_target_obs', C.c_int32),
         ('obs_r', C.c_double * MPE_MAX_AGENTS),
+        ('advfollower', C.c_uint8 * MPE_MAX_AGENTS),
     ]
 
 
@@ -101,6 +102,8 @@ def _load():
             f.restype, f.argtypes = ci, [dp, i64, i64, bp, vp]
         f = getattr(L, 'mpe_reset_' + suf)            # desc, B, ld, seed, episode, env_id0, mask, buffers, stream
         f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, bp, vp]
+        f = getattr(L, 'mpe_target_move_' + suf)      # desc, B, ld, seed, counter, env_id0, buffers, count, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, bp, vp, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci]
     L.mpe_stats_reduce.restype = ci

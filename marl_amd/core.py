@@ -180,6 +180,7 @@ class World(object):
         self._obs_tick = -1        # tick the obs buffer alone corresponds to
         # device reset RNG: Philox key / per-reset counter / global id of env 0 (multi-GPU shards)
         self.seed = 0
+        self.move_counter = 0      # target_move() calls so far (RNG counter of the respawns)
         self.episode = 0
         self.env_id0 = 0
         # scenario kind + reset ranges for the C ABI descriptor (set by the built-in scenarios)
@@ -346,6 +347,7 @@ class World(object):
             d.force_id[i], d.forced_id[i] = int(a.force_id), int(a.forced_id)
             d.advleader[i], d.advsuperleader[i] = int(bool(a.advleader)), int(bool(a.advsuperleader))
             d.obs_r[i] = a.obs_r
+            d.advfollower[i] = int(bool(getattr(a, 'advfollower', False)))
         _hip.check(_hip.lib.mpe_desc_check(d), 'mpe_desc_check')
         self._desc = d
         return d

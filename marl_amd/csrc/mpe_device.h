@@ -43,6 +43,12 @@ struct DevDesc {
   T obs_r2[MPE_MAX_AGENTS];  // obs_r * obs_r, evaluated in T (L1F2_3Targets_100observe.py:206)
 };
 
+// entity sizes alone (kernels that need nothing else of the descriptor)
+template <typename T>
+struct DevSizes {
+  T size[MPE_MAX_ENTITIES];
+};
+
 template <typename T>
 struct KParams {
   const T *act, *noise;

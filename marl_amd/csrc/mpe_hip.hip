@@ -514,6 +514,55 @@ static int reset_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_
   return (int)hipGetLastError();
 }
 
+// target_move (experiments/train_and_eval.py:207-222): one env per lane; the landmarks are independent
+// of each other (a respawn moves only the landmark itself), so the reference's nested loop with
+// `break` is "respawn l iff any follower touches it".
+template <typename T>
+__global__ __launch_bounds__(256) void target_move_kernel(int64_t B, int64_t ld, int A, int L, uint64_t followers,
+                                                           DevSizes<T> sz, uint32_t k0, uint32_t k1,
+                                                           uint32_t counter, uint64_t env_id0, T *pos, int32_t *count) {
+  const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (env >= B) return;
+  const uint64_t gid = env_id0 + (uint64_t)env;
+  int n = 0;
+  for (int l = 0; l < L; ++l) {
+    T *lp = pos + (int64_t)(2 * (A + l)) * ld + env;
+    const T lx = lp[0], ly = lp[ld];
+    bool hit = false;
+    for (int a = 0; a < A; ++a) {
+      if (!((followers >> a) & 1)) continue;
+      const T dx = lx - pos[(int64_t)(2 * a) * ld + env], dy = ly - pos[(int64_t)(2 * a + 1) * ld + env];
+      hit = hit || touching<T>(dx, dy, sz.size[A + l] + sz.size[a]);
+    }
+    if (hit) {
+      uint32_t w[4];
+      philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), counter, 0x80000000u | (uint32_t)l, k0, k1, w);
+      lp[0] = (T)uniform_pm(w[0], w[1], 1.0);
+      lp[ld] = (T)uniform_pm(w[2], w[3], 1.0);
+      ++n;
+    }
+  }
+  if (count != nullptr) count[env] = n;
+}
+
+template <typename T>
+static int target_move_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_t seed, uint32_t counter,
+                            uint64_t env_id0, const mpe_buffers *b, int32_t *count, void *stream) {
+  int rc = check_common<T>(h, B, ld);
+  if (rc) return rc;
+  if (!b || !b->pos) return MPE_ERR_NULL;
+  if (misaligned<T>(b->pos) || misaligned<int32_t>(count)) return MPE_ERR_ALIGN;
+  uint64_t followers = 0;
+  DevSizes<T> sz;
+  for (int a = 0; a < h->n_agents; ++a)
+    if (h->advfollower[a]) followers |= 1ull << a;
+  for (int e = 0; e < h->n_agents + h->n_landmarks; ++e) sz.size[e] = (T)h->size[e];
+  const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+  hipLaunchKernelGGL(target_move_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld, h->n_agents, h->n_landmarks,
+                     followers, sz, (uint32_t)seed, (uint32_t)(seed >> 32), counter, env_id0, (T *)b->pos, count);
+  return (int)hipGetLastError();
+}
+
 // One workgroup per column; rows are summed in a fixed order (thread t takes rows t, t+256, ...
 // sequentially, then a wavefront butterfly, then the 4 wavefront partials in a fixed order), so the
 // result is bitwise reproducible for a given (rows, width).
@@ -553,6 +602,11 @@ extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, do
   extern "C" int mpe_env_step_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, const mpe_buffers *b,   \
                                     void *stream) {                                                            \
     return env_step_impl<T>(d, B, ld, b, stream);                                                              \
+  }                                                                                                            \
+  extern "C" int mpe_target_move_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,       \
+                                       uint32_t counter, uint64_t env_id0, const mpe_buffers *b,               \
+                                       int32_t *count, void *stream) {                                         \
+    return target_move_impl<T>(d, B, ld, seed, counter, env_id0, b, count, stream);                            \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
                                  uint32_t episode, uint64_t env_id0, const uint8_t *mask,                      \

@@ -72,6 +72,7 @@ class ScenarioSpec:
     advsuperleader: Optional[Sequence[bool]] = None
     obs_r: Optional[Sequence[float]] = None          # observation radius
     reward_variant: int = 0                          # 1 = S1L2F2_10Targets_wide_rewardFixed.py
+    advfollower: Optional[Sequence[bool]] = None     # agents whose touch respawns a target (train_and_eval.py:216)
     n_target_obs: int = 3                            # target_pos[0:3]
 
     def __post_init__(self):
@@ -88,6 +89,9 @@ class ScenarioSpec:
             self.advsuperleader = [False] * A
         if self.obs_r is None:
             self.obs_r = [0.0] * A
+        if self.advfollower is None:                 # L1F2_3Targets_100observe.py:40,52,64: the silent adversaries
+            self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind == HIER_PURSUIT
+                                for i in range(A)]
 
     def act_dim(self, i):
         """environment.py:42-76: Discrete(5) for silent agents, MultiDiscrete([0,4],[0,dim_c-1]) otherwise."""
@@ -920,6 +924,57 @@ class BatchedOracle:
         if return_lforce:
             return pos, vel, obs, rew, info, lforce
         return pos, vel, obs, rew, info
+
+
+# --------------------------------------------------------------------------------------
+# target_move (experiments/train_and_eval.py:207-222)          *** parity unpinned ***
+# The reference's tests and fixtures hold nothing for this function and running it here was refused
+# (see DESIGN.md section 4), so this restatement is checked only against itself: serial form
+# (reference loop shape and np.random.rand order) against the vectorised form's decisions.
+# --------------------------------------------------------------------------------------
+def target_move_serial(env: 'SerialEnv'):
+    """train_and_eval.py:212-222 on a SerialEnv: landmarks in order, agents in order, first touching
+    follower respawns the landmark at (rand()*2-1, rand()*2-1) and ends the inner loop."""
+    count = 0
+    for li, land in enumerate(env.landmarks):
+        for ai, agent in enumerate(env.agents):
+            if not env.spec.advfollower[ai]:
+                continue
+            if SerialEnv._touching(land, agent):
+                count += 1
+                land.pos = np.array([np.random.rand() * 2 - 1, np.random.rand() * 2 - 1])
+                break
+    return count
+
+
+def target_move(spec: ScenarioSpec, pos, seed: int, counter: int, env_ids, dtype=np.float64):
+    """Vectorised form with this build's Philox respawn stream (counter = (env_lo, env_hi, move counter,
+    0x80000000 | landmark), key = seed).  Returns (new pos [E,2,B], count [B])."""
+    T = np.dtype(dtype).type
+    A, L = spec.n_agents, spec.n_landmarks
+    pos = np.array(pos, dtype=T)
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    B = env_ids.shape[0]
+    count = np.zeros(B, np.int32)
+    k0 = np.full(B, seed & 0xFFFFFFFF, np.uint32)
+    k1 = np.full(B, (seed >> 32) & 0xFFFFFFFF, np.uint32)
+    c0 = (env_ids & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    c1 = (env_ids >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(all='ignore'):
+        for l in range(L):
+            hit = np.zeros(B, bool)
+            for a in range(A):
+                if not spec.advfollower[a]:
+                    continue
+                d = pos[A + l] - pos[a]
+                hit |= np.sqrt(np.square(d[0]) + np.square(d[1])) < T(spec.size[A + l]) + T(spec.size[a])
+            w = philox4x32_10([c0, c1, np.full(B, counter, np.uint32), np.full(B, 0x80000000 | l, np.uint32)], [k0, k1])
+            nx = (-1.0 + 2.0 * _u01(w[0], w[1])).astype(T)
+            ny = (-1.0 + 2.0 * _u01(w[2], w[3])).astype(T)
+            pos[A + l, 0] = np.where(hit, nx, pos[A + l, 0])
+            pos[A + l, 1] = np.where(hit, ny, pos[A + l, 1])
+            count += hit
+    return pos, count
 
 
 # --------------------------------------------------------------------------------------

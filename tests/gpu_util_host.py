@@ -21,6 +21,7 @@ def desc_from_spec(spec):
         d.force_id[a], d.forced_id[a] = spec.force_id[a], spec.forced_id[a]
         d.advleader[a], d.advsuperleader[a] = int(spec.advleader[a]), int(spec.advsuperleader[a])
         d.obs_r[a] = spec.obs_r[a]
+        d.advfollower[a] = int(spec.advfollower[a])
     d.reward_variant, d.n_target_obs = spec.reward_variant, spec.n_target_obs
     assert _hip.lib.mpe_desc_check(d) == 0
     return d

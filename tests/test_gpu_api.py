@@ -282,3 +282,41 @@ def test_hierarchy_scenarios_episode_loop_matches_oracle(name):
     assert torch.equal(scen.reward(w.agents[0], w), rew_n[0]) and torch.equal(scen.observation(w.agents[-1], w), new_obs_n[-1])
     with pytest.raises(ValueError):
         env.step([torch.zeros(B, 5, device='cuda', dtype=torch.float64)] * env.n)    # leaders need 12 entries
+
+
+def test_training_loop_with_target_move_and_benchmark_reset():
+    """The fork's loop shape (experiments/train_and_eval.py:313-314, :103-126): env.step, then
+    target_move(env); reset_world_for_benchmark as the evaluation env's reset callback."""
+    from marl_amd import make_env
+    from marl_amd.environment import MultiAgentEnv
+    from marl_amd.experiments import target_move, reset_world_for_benchmark
+    B = 512
+    env = make_env('L1F2_3Targets_100observe', benchmark=True, num_envs=B, seed=6)
+    env.reset()
+    w = env.world
+    spec_sizes = [e.size for e in w.entities]
+    total = 0
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for t in range(25):
+        env.step([torch.rand(B, d, generator=gen, device='cuda', dtype=torch.float64) for d in w.act_dims])
+        before = w.pos.clone()
+        cnt = target_move(env)
+        assert cnt.dtype == torch.int32 and tuple(cnt.shape) == (B,)
+        moved = (w.pos != before).any(1)                                  # [E, B]
+        assert not moved[:3].any() and torch.equal(moved[3:].sum(0).int(), cnt)
+        # a landmark moved iff a follower (agents 0, 1) touched it
+        d = (before[3:, None] - before[None, :2]).pow(2).sum(2).sqrt()     # [L, 2, B]
+        dmin = torch.tensor([[spec_sizes[3 + l] + spec_sizes[a] for a in range(2)] for l in range(3)],
+                            device='cuda', dtype=torch.float64)[..., None]
+        assert torch.equal((d < dmin).any(1), moved[3:])
+        total += int(cnt.sum())
+    assert total > 0 and w.move_counter == 25
+    scen = env.reward_callback.__self__
+    ev = MultiAgentEnv(w, reset_world_for_benchmark, scen.reward, scen.observation, scen.benchmark_data)
+    lm = w.pos[3:].clone()
+    obs_n = ev.reset()
+    want = torch.tensor([[-0.5, -0.5], [-0.5, 0.5], [0.5, -0.5]], device='cuda', dtype=torch.float64)
+    for i in range(3):
+        assert torch.equal(w.agents[i].state.p_pos, want[i].expand(B, 2)) and (w.agents[i].state.p_vel == 0).all()
+        assert torch.equal(obs_n[i][:, 2:4], want[i].expand(B, 2))
+    assert torch.equal(w.pos[3:], lm)                                     # landmarks keep their positions

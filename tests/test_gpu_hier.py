@@ -248,3 +248,34 @@ def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, force_tile):
     np.testing.assert_allclose(got[:2 * A], want[:2 * A], rtol=1e-9, atol=1e-6)
     assert got[2 * A + 1] == want[2 * A + 1] and got[2 * A] >= 0
     assert _hip.lib.mpe_info_width(sim.desc) == 1
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+def test_target_move_matches_oracle(golden_dir, dtype):
+    """SURVEY 8f row f3 (experiments/train_and_eval.py:207-222, parity unpinned: see the oracle's
+    header): the kernel respawns exactly the landmarks the oracle does, at the oracle's Philox
+    positions (bit for bit: decisions are evaluated in the kernel's own dtype), and leaves every
+    other entity, the padding and the velocities alone; the draw does not depend on sharding."""
+    spec = O.hier_spec_from_golden(_load(golden_dir, 'h_S1L2F2_10Targets_wide'))
+    B, ld = 3000 + 5, 3200
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    rng = np.random.RandomState(4)
+    pos = (rng.uniform(-1, 1, (spec.n_entities, 2, B)) * np.where(np.arange(B) % 2, 0.15, 1.0)).astype(npdt)
+    sim = HipSim(spec, B, dtype, ld)
+    sim.set_state(pos, np.zeros((spec.n_agents, 2, B)))
+    count = torch.full((ld,), -7, dtype=torch.int32, device='cuda')
+    fn = getattr(lib, 'mpe_target_move_' + sim.suf)
+    assert fn(sim.desc, B, ld, 99, 3, 1000, sim.buffers(), count.data_ptr(), sim.stream) == 0
+    want_pos, want_cnt = O.target_move(spec, pos, seed=99, counter=3, env_ids=np.arange(B, dtype=np.uint64) + 1000,
+                                       dtype=npdt)
+    got = sim.pos[..., :B].cpu().numpy()
+    assert np.array_equal(got, want_pos)
+    assert np.array_equal(count[:B].cpu().numpy(), want_cnt) and (count[B:] == -7).all()
+    assert want_cnt.sum() > 100 and (want_cnt[::2] == 0).mean() > 0.5
+    assert (sim.pos[..., B:] == 0).all() and (sim.vel == 0).all()
+    # second shard geometry: envs [1500, B) alone give the same rows
+    sim2 = HipSim(spec, B - 1500, dtype)
+    sim2.set_state(pos[..., 1500:], np.zeros((spec.n_agents, 2, B - 1500)))
+    assert fn(sim2.desc, B - 1500, B - 1500, 99, 3, 2500, sim2.buffers(), None, sim2.stream) == 0
+    assert np.array_equal(sim2.pos.cpu().numpy(), want_pos[..., 1500:])
+    assert fn(sim.desc, B, ld, 99, 3, 1000, None, None, sim.stream) == -1

@@ -22,7 +22,7 @@ def _declared_functions():
 def test_library_exports_every_declared_symbol():
     from marl_amd import _hip
     names = _declared_functions()
-    assert len(names) >= 21 and 'mpe_env_step_f32' in names and 'mpe_reset_f64' in names
+    assert len(names) >= 23 and 'mpe_target_move_f64' in names and 'mpe_env_step_f32' in names and 'mpe_reset_f64' in names
     raw = ctypes.CDLL(_hip._LIB_PATH)
     for n in names:
         assert hasattr(raw, n), 'libmpe_hip.so does not export %s' % n
@@ -99,6 +99,8 @@ def test_descriptor_validation_and_error_codes():
     assert lib.mpe_world_step_f32(d, 4, 4, buf(act=8, vel=8), None) == -1
     assert lib.mpe_observe_f32(d, 4, 4, buf(pos=8, vel=8), None) == -1
     assert lib.mpe_reset_f32(d, 4, 4, 0, 0, 0, None, buf(vel=8), None) == -1
+    assert lib.mpe_target_move_f32(d, 4, 4, 0, 0, 0, buf(), None, None) == -1
+    assert lib.mpe_target_move_f64(d, 4, 4, 0, 0, 0, buf(pos=12), None, None) == -4
     # goal scenarios need the goal pointer; scenarios without benchmark_data ignore `info`
     da = _desc(O.simple_adversary_spec())
     assert lib.mpe_env_step_f32(da, 4, 4, buf(obs=8, rew=8, **ok), None) == -1

@@ -275,3 +275,31 @@ def test_reset_positions_ranges_and_independence():
     q = O.reset_positions(spec, seed=7, episode=3, env_ids=ids[1000:2000])
     assert np.array_equal(q, p[:, :, 1000:2000])
     assert not np.array_equal(O.reset_positions(spec, 7, 4, ids), p)
+
+
+def test_target_move_oracle_forms_agree(golden_dir):
+    """SURVEY 8f row f3, experiments/train_and_eval.py:207-222.  PARITY UNPINNED: no reference fixture
+    covers target_move and running the reference function here was refused, so the
+    two restatements are only checked against each other: the serial form (reference loop shape) and
+    the vectorised form must respawn the same landmarks and report the same count; untouched entities
+    keep their positions; respawned ones land in [-1, 1)^2."""
+    g = _load(golden_dir, 'h_S1L2F2_10Targets_wide_dense')
+    spec = O.hier_spec_from_golden(g)
+    assert spec.advfollower == [True, True, False, False, False]
+    A = spec.n_agents
+    total = 0
+    for s in range(g['pos'].shape[0]):
+        for t in (0, 5, 24, 100, 105, 124):
+            pos = g['pos'][s, t % 100] * (0.12 if t >= 100 else 1.0)   # [E,2]; t >= 100: a crowded copy
+            env = O.SerialEnv(spec)
+            env.set_state(pos, g['vel'][s, t % 100])
+            np.random.seed(s)
+            n = O.target_move_serial(env)
+            after = env.get_state()[0]
+            bpos, cnt = O.target_move(spec, pos[:, :, None], seed=7, counter=t, env_ids=[s])
+            moved = np.any(after != pos, axis=1)
+            assert cnt[0] == n == moved.sum() and not moved[:A].any()
+            assert np.array_equal(np.any(bpos[:, :, 0] != pos, axis=1), moved)
+            assert (np.abs(bpos[:, :, 0][moved]) <= 1).all() and (np.abs(after[moved]) <= 1).all()
+            total += n
+    assert total > 10
