@@ -122,17 +122,30 @@ struct Win {
   int64_t ld;
 
   __device__ __forceinline__ Win(const T *base_, int64_t ld_) : base(const_cast<T *>(base_)), ld(ld_) {}
+#ifdef MPE_WIN_SADDR
+  // row base pinned in SGPRs + zero-extended 32-bit lane byte offset -> `global_* v, v_off, s[base]`
+  __device__ __forceinline__ T *at(int row, uint32_t lane) const {
+    const uint64_t b = reinterpret_cast<uint64_t>(base + (int64_t)row * ld);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    typedef __attribute__((address_space(1))) char gchar;
+    gchar *g = reinterpret_cast<gchar *>(((uint64_t)bhi << 32) | blo);
+    return (T *)(g + (uint64_t)(lane * (uint32_t)sizeof(T)));
+  }
+#else
+  __device__ __forceinline__ T *at(int row, uint32_t lane) const { return base + (int64_t)row * ld + lane; }
+#endif
   __device__ __forceinline__ T ld_state(int row, uint32_t lane) const {
-    return mpe::ld_state(base + (int64_t)row * ld + (lane == kNoLane ? 0u : lane));
+    return mpe::ld_state(at(row, lane == kNoLane ? 0u : lane));
   }
   __device__ __forceinline__ T ld_stream(int row, uint32_t lane) const {
-    return mpe::ld_stream(base + (int64_t)row * ld + (lane == kNoLane ? 0u : lane));
+    return mpe::ld_stream(at(row, lane == kNoLane ? 0u : lane));
   }
   __device__ __forceinline__ void st_state(int row, uint32_t lane, T v) const {
-    if (lane != kNoLane) mpe::st_state(base + (int64_t)row * ld + lane, v);
+    if (lane != kNoLane) mpe::st_state(at(row, lane), v);
   }
   __device__ __forceinline__ void st_stream(int row, uint32_t lane, T v) const {
-    if (lane != kNoLane) mpe::st_stream(base + (int64_t)row * ld + lane, v);
+    if (lane != kNoLane) mpe::st_stream(at(row, lane), v);
   }
 };
 

@@ -114,6 +114,15 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         lfy[a] = lfy[a] + fy;
       }
     }
+    // core.py:226-230 (agent.state.c = action.c), written here so that the command entries die early
+    if (p.comm != nullptr) {
+      const Win<T> wcomm(p.comm + blk0, ld);
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+          wcomm.st_state(a * C + k, lo, a < NF ? T(0) : c[a < NF ? 0 : a - NF][k]);
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:199-205, b ascending; only a is pushed
 #pragma unroll
@@ -144,14 +153,6 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         wlf.st_state(2 * a, lo, lfx[a]);
         wlf.st_state(2 * a + 1, lo, lfy[a]);
       }
-    }
-    if (p.comm != nullptr) {  // core.py:226-230
-      const Win<T> wcomm(p.comm + blk0, ld);
-#pragma unroll
-      for (int a = 0; a < A; ++a)
-#pragma unroll
-        for (int k = 0; k < C; ++k)
-          wcomm.st_state(a * C + k, lo, a < NF ? T(0) : c[a < NF ? 0 : a - NF][k]);
     }
   } else if (DO_OBS && p.lforce != nullptr) {
     const Win<T> wlf0(p.lforce + blk0, ld);
