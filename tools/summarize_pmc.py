@@ -32,6 +32,23 @@ def main():
             w, _ = write[k]
             out['kernels'][k] = {'launches': n, 'fetch_bytes': f * 1024 * 2, 'write_bytes': w * 1024,
                                  'traffic_bytes': f * 1024 * 2 + w * 1024}
+    # optional third pass: SQ issue counters (quad-cycle units, summed over the chip) + GRBM_GUI_ACTIVE
+    # (summed over the 8 XCDs): VALU utilisation = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel cycles)
+    import os
+    sq_path = src + '/sq_counter_collection.csv'
+    if os.path.exists(sq_path):
+        names = ['SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
+                 'SQ_ACTIVE_INST_ANY', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE']
+        per = {n: per_kernel(sq_path, n) for n in names}
+        for k in out['kernels']:
+            if k not in per['GRBM_GUI_ACTIVE']:
+                continue
+            c = {n: per[n][k][0] for n in names if k in per[n]}
+            cycles = c['GRBM_GUI_ACTIVE'] / 8.0
+            c['kernel_cycles'] = cycles
+            c['valu_util'] = c['SQ_ACTIVE_INST_VALU'] * 4.0 / (1024.0 * cycles)
+            c['wave_wait_frac'] = c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']
+            out['kernels'][k]['sq'] = c
     json.dump(out, open(dst, 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
