@@ -40,7 +40,12 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   T *sAux = sVel;  // valid only after the observation phase
 
   const int lane = threadIdx.x % TILE;
-  const int chunk = threadIdx.x / TILE;
+  // f32: a chunk is a whole wavefront, so the chunk index -- and with it every agent index, loop
+  // bound and descriptor lookup below -- is wave-uniform.  Saying so (readfirstlane) turns the
+  // per-agent loops into scalar loops with scalar descriptor loads; left as a per-lane value the
+  // compiler ran them as exec-masked vector loops and fetched d.size[b] with a vector load + full
+  // wait inside the pair loop.  f64 (two chunks per wavefront) keeps the per-lane form.
+  const int chunk = TILE == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TILE)) : (int)(threadIdx.x / TILE);
   const int64_t ld = p.ld;
   const int64_t ntiles = (p.B + TILE - 1) / TILE;
 
