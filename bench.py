@@ -153,9 +153,10 @@ def main():
         """Soft one-hot actions in the kernel's SoA layout: softmax over each agent's 5 physical entries
         (and, for a non-silent agent, over its dim_c command entries)."""
         w = env.world
+        a = w.new_action_buffer()          # the world's padded row stride: env.step adopts it without a copy
         if w.act.dim() == 3:
-            return torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1).contiguous()
-        a = torch.empty_like(w.act_rows)
+            a.copy_(torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1))
+            return a
         for r0, d in zip(w.act_row0, w.act_dims):
             for lo, hi in ((r0, r0 + 5), (r0 + 5, r0 + d)):
                 if hi > lo:
@@ -241,7 +242,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if dtype == torch.float32 else 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'scenario': scenario, 'envs_per_gpu': B,
+            'config': {'workload': args.workload, 'scenario': scenario, 'envs_per_gpu': B, 'row_stride': env.world.ld,
                        'agents': n, 'entities': len(env.world.entities), 'episode_len': EPISODE_LEN,
                        'actions': 'softmax(N(0,1)) soft one-hot, %d resident buffers rotated' % len(pool),
                        'reset_in_timed_region': True, 'benchmark_info': has_info,

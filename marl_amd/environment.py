@@ -8,7 +8,8 @@
 ``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190; ``[B, 5 +
 dim_c]`` for a non-silent agent, whose space is MultiDiscrete: 5 physical entries then the dim_c comm
 entries, environment.py:161-168), one tensor ``[B, n, 5]``, or one contiguous tensor ``[n, 5, B]`` /
-``[act_total, B]`` (the kernel's SoA layout, used in place).  Policies can write straight into
+``[act_total, B]`` (the kernel's SoA layout; used in place when it has the world's padded row stride,
+i.e. comes from ``env.world.new_action_buffer()``).  Policies can write straight into
 ``env.action_views[i]`` (``[B, act_dim_i]`` views of the kernel's SoA action buffer) and pass that
 list: then step() copies nothing.
 Returned tensors are views of buffers that the next step()/reset() overwrites.
@@ -81,12 +82,19 @@ class MultiAgentEnv(object):
     # -- environment.py:157-208: the decode itself runs inside the kernel ------------------------------
     def _set_actions(self, action_n):
         act = self.world.act
-        if torch.is_tensor(action_n) and action_n.dim() == act.dim() and action_n.is_contiguous() \
+        if torch.is_tensor(action_n) and action_n.dim() == act.dim() \
                 and tuple(action_n.shape) == tuple(act.shape) and action_n.dtype == act.dtype \
                 and action_n.device == act.device and (self.num_envs, self.n) != (5, 5):
-            # SoA fast path: a contiguous [n, 5, B] tensor is the kernel's own layout; adopt it in
-            # place (no copy).  env.action_views keep pointing at the env's original buffer.
-            self.world.act = action_n
+            # SoA path: an [n, 5, B] ([act_total, B]) tensor is the kernel's own layout.  With the
+            # world's row stride (world.new_action_buffer()) it is adopted in place, no copy;
+            # env.action_views keep pointing at the env's original buffer.  Any other strides: one
+            # row-wise copy into the env's buffer.
+            if action_n.stride() == self._own_act.stride():
+                self.world.act = action_n
+                return
+            if act.data_ptr() != self._own_act.data_ptr():
+                self.world.act = act = self._own_act
+            act.copy_(action_n)
             return
         if act.data_ptr() != self._own_act.data_ptr():
             self.world.act = act = self._own_act

@@ -19,7 +19,7 @@ def target_move(env):
     d = w.descriptor()
     count = torch.empty(w.num_envs, dtype=torch.int32, device=w.device)
     fn = getattr(_hip.lib, 'mpe_target_move_' + _hip.suffix(w.dtype))
-    _hip.check(fn(d, w.num_envs, w.num_envs, w.seed, w.move_counter, w.env_id0, _hip.Buffers(pos=w.pos),
+    _hip.check(fn(d, w.num_envs, w.ld, w.seed, w.move_counter, w.env_id0, _hip.Buffers(pos=w.pos),
                   count.data_ptr(), _hip.stream_of(w.device)), 'mpe_target_move')
     w.move_counter += 1
     w.mark_dirty()
