@@ -12,12 +12,15 @@ using namespace mpe;
 #ifndef TT
 #define TT float
 #endif
-#ifndef THREADS
-#define THREADS 256
+#ifndef BENCH_THREADS
+#define BENCH_THREADS 256
 #endif
 typedef TT T;
 int main() {
-  const int64_t B = 1 << 20;
+#ifndef PAD
+#define PAD 256
+#endif
+  const int64_t B = 1 << 20, LD = B + PAD;  // row stride off the power of two (core.py:padded_stride)
   constexpr int A = 4, L = 2, E = 6;
   KParams<T> p{};
   DevDesc<T> &d = p.d;
@@ -33,19 +36,19 @@ int main() {
   }
   for (int e = A; e < E; ++e) { d.size[e] = 0.2f; d.collide[0] |= 1u << e; }
   d.obs_total = row;
-  std::vector<T> h((size_t)32 * B);
+  std::vector<T> h((size_t)32 * LD);
   uint32_t s = 12345;
   for (auto &x : h) { s = s * 1664525u + 1013904223u; x = ((s >> 8) & 0xFFFF) / 65536.f * 2.f - 1.f; }
   T *pos, *vel, *act, *obs, *rew, *info;
   const size_t es = sizeof(T);
-  CK(hipMalloc(&pos, 2 * E * B * es)); CK(hipMalloc(&vel, 2 * A * B * es)); CK(hipMalloc(&act, 5 * A * B * es));
-  CK(hipMalloc(&obs, (size_t)row * B * es)); CK(hipMalloc(&rew, A * B * es)); CK(hipMalloc(&info, A * B * es));
-  CK(hipMemcpy(pos, h.data(), 2 * E * B * es, hipMemcpyHostToDevice));
-  CK(hipMemset(vel, 0, 2 * A * B * es));
-  CK(hipMemcpy(act, h.data(), 5 * A * B * es, hipMemcpyHostToDevice));
-  p.act = act; p.pos = pos; p.vel = vel; p.obs = obs; p.rew = rew; p.info = info; p.B = B; p.ld = B;
-  const dim3 grid((unsigned)(B / THREADS)), block(THREADS);
-  auto kern = small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, THREADS, false, true, true>;
+  CK(hipMalloc(&pos, 2 * E * LD * es)); CK(hipMalloc(&vel, 2 * A * LD * es)); CK(hipMalloc(&act, 5 * A * LD * es));
+  CK(hipMalloc(&obs, (size_t)row * LD * es)); CK(hipMalloc(&rew, A * LD * es)); CK(hipMalloc(&info, A * LD * es));
+  CK(hipMemcpy(pos, h.data(), 2 * E * LD * es, hipMemcpyHostToDevice));
+  CK(hipMemset(vel, 0, 2 * A * LD * es));
+  CK(hipMemcpy(act, h.data(), 5 * A * LD * es, hipMemcpyHostToDevice));
+  p.act = act; p.pos = pos; p.vel = vel; p.obs = obs; p.rew = rew; p.info = info; p.B = B; p.ld = LD;
+  const dim3 grid((unsigned)(B / BENCH_THREADS)), block(BENCH_THREADS);
+  auto kern = small_kernel<T, MPE_SIMPLE_TAG, 4, 2, 3, BENCH_THREADS, false, true, true>;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, grid, block, 0, 0, p);
   CK(hipEventRecord(e0));
@@ -54,6 +57,6 @@ int main() {
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double bytes = (double)(5 * A + 2 * E + 2 * A + 4 * A + row + A + A) * es * B;
-  printf("%-34s T=%4d %s: %7.1f us  %6.0f GB/s\n", VARIANT, THREADS, sizeof(T) == 4 ? "f32" : "f64", ms / iters * 1e3, bytes / (ms / iters) / 1e6);
+  printf("%-34s T=%4d %s: %7.1f us  %6.0f GB/s\n", VARIANT, BENCH_THREADS, sizeof(T) == 4 ? "f32" : "f64", ms / iters * 1e3, bytes / (ms / iters) / 1e6);
   return 0;
 }
