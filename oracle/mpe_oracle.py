@@ -38,6 +38,11 @@ SIMPLE = 2             # build/lib/multiagent/scenarios/simple.py            (SU
 SIMPLE_ADVERSARY = 3   # build/lib/multiagent/scenarios/simple_adversary.py
 SIMPLE_PUSH = 4        # build/lib/multiagent/scenarios/simple_push.py
 HIER_PURSUIT = 5       # multiagent/scenarios/{L1F*,S1L*}.py: the fork's leader/follower pursuit
+SPEAKER_LISTENER = 6   # build/lib/multiagent/scenarios/simple_speaker_listener.py  (comm half)
+SIMPLE_REFERENCE = 7   # build/lib/multiagent/scenarios/simple_reference.py
+COMM_KINDS = (SPEAKER_LISTENER, SIMPLE_REFERENCE)   # per-agent goal landmark (agent.goal_b) + observed comm
+# landmark.color tables (simple_speaker_listener.py:48-50 / simple_reference.py:41-43): (base, highlighted)
+COMM_COLORS = {SPEAKER_LISTENER: (0.15, 0.65), SIMPLE_REFERENCE: (0.25, 0.75)}
 GOAL_KINDS = (SIMPLE_ADVERSARY, SIMPLE_PUSH)   # scenarios with a per-env goal landmark (agent.goal_a)
 
 
@@ -95,7 +100,19 @@ class ScenarioSpec:
 
     def act_dim(self, i):
         """environment.py:42-76: Discrete(5) for silent agents, MultiDiscrete([0,4],[0,dim_c-1]) otherwise."""
-        return 5 + (0 if self.silent[i] else self.dim_c)
+        return (5 if self.movable[i] else 0) + (0 if self.silent[i] else self.dim_c)   # environment.py:51-63
+
+    def comm_row0(self, i):
+        """First comm entry inside agent i's action (after the physical part, if it has one)."""
+        return 5 if self.movable[i] else 0
+
+    @property
+    def goal_rows(self):
+        """Rows of the per-env goal index buffer: agent.goal_a of simple_adversary / simple_push (1),
+        agent 0's goal_b of simple_speaker_listener (1), every agent's goal_b of simple_reference (A)."""
+        if self.kind in GOAL_KINDS or self.kind == SPEAKER_LISTENER:
+            return 1
+        return self.n_agents if self.kind == SIMPLE_REFERENCE else 0
 
     @property
     def act_dims(self):
@@ -116,6 +133,10 @@ class ScenarioSpec:
             return 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others
         if self.kind == HIER_PURSUIT:           # L1F2_3Targets_100observe.py:250-253
             return 4 + 4 * (A - 1) + (2 if self.forced_id[i] >= 0 else 0) + 2 * min(L, self.n_target_obs)
+        if self.kind == SPEAKER_LISTENER:       # simple_speaker_listener.py:89-94
+            return 3 if not self.movable[i] else 2 + 2 * L + self.dim_c * (A - 1)
+        if self.kind == SIMPLE_REFERENCE:       # simple_reference.py:89
+            return 2 + 2 * L + 3 + self.dim_c * (A - 1)
         if self.kind == SIMPLE:                 # simple.py:50
             return 2 + 2 * L
         if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:137-140
@@ -132,7 +153,7 @@ class ScenarioSpec:
     def info_width(self):
         if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:58-67 (tuple of L+1 for good agents)
             return self.n_landmarks + 1
-        if self.kind in (SIMPLE, SIMPLE_PUSH):  # no benchmark_data in these scenarios
+        if self.kind in (SIMPLE, SIMPLE_PUSH) + COMM_KINDS:  # no (working) benchmark_data in these scenarios
             return 0
         return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT) else 4
 
@@ -180,6 +201,24 @@ def hier_spec_from_golden(g):
         forced_id=[int(x) for x in g['spec_forced_id']], advleader=[bool(x) for x in g['spec_advleader']],
         advsuperleader=[bool(x) for x in g['spec_advsuperleader']], obs_r=[float(x) for x in g['spec_obs_r']],
         reward_variant=int(g['spec_reward_variant']))
+
+
+def speaker_listener_spec():
+    """simple_speaker_listener.py:10-34: agent 0 = speaker (fixed, speaks), agent 1 = listener (silent)."""
+    return ScenarioSpec(
+        kind=SPEAKER_LISTENER, n_agents=2, n_landmarks=3, adversary=[False, False],
+        size=[0.075, 0.075, 0.04, 0.04, 0.04], accel=[None, None], max_speed=[None, None],
+        collide=[False] * 5, movable=[False, True, False, False, False], u_noise=[None, None], mass=[1.0] * 5,
+        agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=3, silent=[False, True])
+
+
+def simple_reference_spec():
+    """simple_reference.py:6-25: two movable agents that both speak (dim_c = 10)."""
+    return ScenarioSpec(
+        kind=SIMPLE_REFERENCE, n_agents=2, n_landmarks=3, adversary=[False, False],
+        size=[0.05] * 5, accel=[None, None], max_speed=[None, None],
+        collide=[False] * 5, movable=[True, True, False, False, False], u_noise=[None, None], mass=[1.0] * 5,
+        agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=10, silent=[False, False])
 
 
 def simple_spec():
@@ -254,6 +293,7 @@ class SerialEnv:
         self.landmarks = self.bodies[spec.n_agents:]
         self.n = spec.n_agents
         self.goal = 0        # index of the goal landmark (agent.goal_a), GOAL_KINDS only
+        self.goals = [0] * spec.n_agents   # agent.goal_b landmark index, COMM_KINDS only
 
     # -- state helpers ----------------------------------------------------------------
     def set_state(self, pos, vel):
@@ -270,6 +310,10 @@ class SerialEnv:
         s = self.spec
         if s.kind in GOAL_KINDS:   # goal = np.random.choice(world.landmarks) (simple_adversary.py:45)
             self.goal = int(np.random.choice(len(self.landmarks)))
+        if s.kind == SPEAKER_LISTENER:   # simple_speaker_listener.py:43
+            self.goals[0] = int(np.random.choice(len(self.landmarks)))
+        if s.kind == SIMPLE_REFERENCE:   # simple_reference.py:34,36
+            self.goals = [int(np.random.choice(len(self.landmarks))) for _ in self.agents]
         for a in self.agents:
             a.pos = np.random.uniform(-s.agent_pos_range, +s.agent_pos_range, 2)
             a.vel = np.zeros(2)
@@ -282,12 +326,15 @@ class SerialEnv:
     # -- environment.py:157-208 (Discrete(5) soft one-hot path) --------------------------
     def _decode_action(self, agent, action):
         u = np.zeros(2)
-        u[0] += action[1] - action[2]
-        u[1] += action[3] - action[4]
-        u *= 5.0 if agent.accel is None else agent.accel
+        c0 = 0
+        if agent.movable:                 # environment.py:174-197: only a movable agent has the physical part
+            u[0] += action[1] - action[2]
+            u[1] += action[3] - action[4]
+            u *= 5.0 if agent.accel is None else agent.accel
+            c0 = 5
         agent.u = u
         # environment.py:161-168,198-206: a non-silent agent's action carries dim_c comm entries
-        agent.c_act = np.zeros(self.spec.dim_c) if agent.silent else np.asarray(action[5:5 + self.spec.dim_c])
+        agent.c_act = np.zeros(self.spec.dim_c) if agent.silent else np.asarray(action[c0:c0 + self.spec.dim_c])
 
     # -- core.py:153-194 (fork): leaders push the agents they command ------------------------------------
     def _apply_leader_force(self, force):
@@ -468,6 +515,17 @@ class SerialEnv:
         kind = self.spec.kind
         if kind == HIER_PURSUIT:
             return self._hier_observation(i)
+        if kind in COMM_KINDS:
+            base, hi = COMM_COLORS[kind]
+            color = np.full(3, base)
+            color[self.goals[i]] = hi                            # agent.goal_b.color
+            rel_lm = [lm.pos - me.pos for lm in self.landmarks]
+            comm = [o.comm for o in self.agents if o is not me]
+            if kind == SIMPLE_REFERENCE:                         # simple_reference.py:62-89
+                return np.concatenate([me.vel] + rel_lm + [color] + comm)
+            if not me.movable:                                   # simple_speaker_listener.py:89-91
+                return np.concatenate([color])
+            return np.concatenate([me.vel] + rel_lm + comm)      # :93-94
         if kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
             goal = self.landmarks[self.goal]
             rel_lm = [lm.pos - me.pos for lm in self.landmarks]
@@ -500,6 +558,10 @@ class SerialEnv:
         kind = self.spec.kind
         if kind == HIER_PURSUIT:
             return self._hier_reward(i)
+        if kind == SPEAKER_LISTENER:                             # simple_speaker_listener.py:66-70
+            return -self._sq(self.agents[1], self.landmarks[self.goals[0]])
+        if kind == SIMPLE_REFERENCE:                             # simple_reference.py:56-60 (goal_a = the other agent)
+            return -self._sq(self.agents[1 - i], self.landmarks[self.goals[i]])
         if kind == SIMPLE:                                       # simple.py:41-43
             return -self._sq(me, self.landmarks[0])
         if kind in GOAL_KINDS:
@@ -636,7 +698,8 @@ class BatchedOracle:
                 if s.force_id[l] < 0 or s.forced_id[i] != s.force_id[l]:
                     continue
                 # a silent agent's action.c stays zeros(dim_c) (environment.py:80,198-206)
-                c = (np.zeros((s.dim_c, B), T) if s.silent[l] else act[offs[l] + 5:offs[l] + 5 + s.dim_c])
+                c = (np.zeros((s.dim_c, B), T) if s.silent[l]
+                     else act[offs[l] + s.comm_row0(l):offs[l] + s.comm_row0(l) + s.dim_c])
                 if s.advsuperleader[l]:
                     lf[i] = c[0:2]
                     continue
@@ -671,6 +734,8 @@ class BatchedOracle:
         lforce = None
         with np.errstate(all='ignore'):
             for i in range(A):
+                if not s.movable[i]:          # no physical part in its action (environment.py:174)
+                    continue
                 sens = T(5.0 if s.accel[i] is None else s.accel[i])
                 a = act[offs[i]:offs[i] + 5]
                 u = np.stack([(a[1] - a[2]) * sens, (a[3] - a[4]) * sens])
@@ -710,6 +775,47 @@ class BatchedOracle:
         if return_lforce:
             return pos, vel, (lforce if lforce is not None else np.zeros((A, 2, pos.shape[-1]), T))
         return pos, vel
+
+    def comm_state(self, act):
+        """agent.state.c after a step (core.py:224-230): the comm entries of the action for agents that
+        speak, zeros for silent ones.  [A, dim_c, B]."""
+        s, T = self.spec, self.dt
+        act = np.asarray(act, dtype=T)
+        if act.ndim == 3:
+            act = act.reshape(-1, act.shape[-1])
+        offs = np.concatenate([[0], np.cumsum(s.act_dims)])
+        c = np.zeros((s.n_agents, s.dim_c, act.shape[-1]), T)
+        for i in range(s.n_agents):
+            if not s.silent[i]:
+                c[i] = act[offs[i] + s.comm_row0(i):offs[i] + s.comm_row0(i) + s.dim_c]
+        return c
+
+    def _observe_comm(self, pos, vel, goal, comm):
+        """simple_speaker_listener.py:66-94 / simple_reference.py:56-89.  goal: [goal_rows, B] landmark index of
+        agent.goal_b; comm: agent.state.c [A, dim_c, B]."""
+        s, T = self.spec, self.dt
+        A, L = s.n_agents, s.n_landmarks
+        B = pos.shape[-1]
+        goal = np.asarray(goal, np.int64).reshape(-1, B)
+        comm = np.zeros((A, s.dim_c, B), T) if comm is None else np.asarray(comm, T)
+        base, hi = COMM_COLORS[s.kind]
+        sq = lambda p, q: np.square(p[0] - q[0]) + np.square(p[1] - q[1])
+        lm_of = lambda g: pos[A:][g, :, np.arange(B)].T            # [2,B] position of landmark g[b]
+        obs, rew = [], np.zeros((A, B), T)
+        for i in range(A):
+            g = goal[i if s.kind == SIMPLE_REFERENCE else 0]
+            color = np.full((3, B), base, T)
+            color[g, np.arange(B)] = T(hi)
+            rel_lm = [pos[A + l] - pos[i] for l in range(L)]
+            other_c = [comm[j] for j in range(A) if j != i]
+            if s.kind == SIMPLE_REFERENCE:
+                rows = [vel[i]] + rel_lm + [color] + other_c
+                rew[i] = -sq(pos[1 - i], lm_of(g))
+            else:
+                rows = [color] if not s.movable[i] else [vel[i]] + rel_lm + other_c
+                rew[i] = -sq(pos[1], lm_of(g))
+            obs.append(np.concatenate(rows, axis=0))
+        return obs, rew, np.zeros((A, 0, B), T)
 
     def _observe_hier(self, pos, vel, lforce):
         """L1F*/S1L* gathers, vectorised (e.g. L1F2_3Targets_100observe.py:136-253)."""
@@ -847,7 +953,7 @@ class BatchedOracle:
                         rew[i] = -np.sqrt(sq(pos[i], gp))
         return obs, rew, info
 
-    def observe(self, pos, vel, want_info=True, goal=None, lforce=None):
+    def observe(self, pos, vel, want_info=True, goal=None, lforce=None, comm=None):
         """Returns obs (list of [dim_i, B]), rew [A,B], info [A,W,B]."""
         s, T = self.spec, self.dt
         A, L, E = s.n_agents, s.n_landmarks, s.n_entities
@@ -860,6 +966,9 @@ class BatchedOracle:
             return obs, rew, (info if want_info else None)
         if s.kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
             obs, rew, info = self._observe_f1(pos, vel, goal)
+            return obs, rew, (info if want_info else None)
+        if s.kind in COMM_KINDS:
+            obs, rew, info = self._observe_comm(pos, vel, goal, comm)
             return obs, rew, (info if want_info else None)
         obs = []
         for i in range(A):
@@ -920,7 +1029,8 @@ class BatchedOracle:
 
     def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False):
         pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True)
-        obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce)
+        obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce,
+                                      comm=self.comm_state(act) if self.spec.kind in COMM_KINDS else None)
         if return_lforce:
             return pos, vel, obs, rew, info, lforce
         return pos, vel, obs, rew, info
@@ -1018,7 +1128,10 @@ def reset_goals(spec: ScenarioSpec, seed: int, episode, env_ids):
     k0 = np.full(B, seed & 0xFFFFFFFF, np.uint32)
     k1 = np.full(B, (seed >> 32) & 0xFFFFFFFF, np.uint32)
     w = philox4x32_10([lo, hi, episode, np.full(B, 0xFFFFFFFF, np.uint32)], [k0, k1])
-    return ((w[0].astype(np.uint64) * np.uint64(spec.n_landmarks)) >> np.uint64(32)).astype(np.int32)
+    pick = lambda word: ((word.astype(np.uint64) * np.uint64(spec.n_landmarks)) >> np.uint64(32)).astype(np.int32)
+    if spec.goal_rows > 1:      # simple_reference: one goal per agent from words 0, 1, ... of the same draw
+        return np.stack([pick(w[r]) for r in range(spec.goal_rows)])
+    return pick(w[0])
 
 
 def reset_positions(spec: ScenarioSpec, seed: int, episode, env_ids, dtype=np.float64):

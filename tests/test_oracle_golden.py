@@ -303,3 +303,56 @@ def test_target_move_oracle_forms_agree(golden_dir):
             assert (np.abs(bpos[:, :, 0][moved]) <= 1).all() and (np.abs(after[moved]) <= 1).all()
             total += n
     assert total > 10
+
+
+COMM_CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec)]
+
+
+@pytest.mark.parametrize('name,mk', COMM_CASES)
+def test_serial_oracle_comm_scenarios_bit_exact(golden_dir, name, mk):
+    """SURVEY 8f row f1, the speaking scenarios: ragged actions (a fixed speaker has no physical
+    part, environment.py:174), agent.state.c, per-agent goal_b, incl. the reference's np.random
+    order at reset (np.random.choice for the goals first)."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    assert spec.act_dims == list(g['act_dims']) and spec.size == list(g['spec_size'])
+    assert spec.movable == list(g['spec_movable']) and spec.silent == list(g['spec_silent'])
+    assert not g['spec_shared_reward']
+    offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    S, T = g['act'].shape[:2]
+    for s in range(S):
+        np.random.seed(int(g['seeds'][s]))
+        env = O.SerialEnv(spec, benchmark=False)
+        env.reset()                                      # make_world() resets once ...
+        obs0 = env.reset()                               # ... and env.reset() again
+        want_goal = [int(x) for x in g['goal'][s]]
+        got_goal = env.goals if spec.kind == O.SIMPLE_REFERENCE else [env.goals[0], -1]
+        assert got_goal == want_goal
+        assert np.array_equal(np.concatenate(obs0), g['obs0'][s])
+        for t in range(T):
+            obs_n, rew_n, _, _ = env.step([g['act'][s, t, offs[i]:offs[i + 1]] for i in range(spec.n_agents)])
+            pos, vel = env.get_state()
+            assert np.array_equal(pos, g['pos'][s, t]) and np.array_equal(vel, g['vel'][s, t])
+            assert np.array_equal(np.stack([a.comm for a in env.agents]), g['comm'][s, t])
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
+            assert np.array_equal(np.asarray(rew_n, float), g['rew'][s, t]), (name, s, t)
+
+
+@pytest.mark.parametrize('name,mk', COMM_CASES)
+def test_batched_oracle_comm_scenarios_bit_exact(golden_dir, name, mk):
+    g = _load(golden_dir, name)
+    spec = mk()
+    bo = O.BatchedOracle(spec)
+    S, T = g['act'].shape[:2]
+    goal = np.maximum(g['goal'].T[:spec.goal_rows], 0)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    obs, _, _ = bo.observe(pos, vel, goal=goal, comm=np.moveaxis(g['comm0'], 0, -1))
+    assert np.array_equal(np.concatenate(obs, 0), g['obs0'].T)
+    for t in range(T):
+        act = g['act'][:, t].T
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, goal=goal)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)) and np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1))
+        assert np.array_equal(bo.comm_state(act), np.moveaxis(g['comm'][:, t], 0, -1))
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
