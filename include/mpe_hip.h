@@ -63,6 +63,10 @@ extern "C" {
 #define MPE_HIER_PURSUIT 5  /* multiagent/scenarios/L1F..py and S1L..py: the fork's follower / leader /
                                super-leader pursuit family (leader force core.py:153-194, masked +
                                distance-sorted observations, hierarchical rewards)               */
+#define MPE_SPEAKER_LISTENER 6 /* build/lib/multiagent/scenarios/simple_speaker_listener.py: agent 0 fixed and
+                                  speaking, agent 1 moving and silent; per-env goal landmark (agent 0's goal_b) */
+#define MPE_SIMPLE_REFERENCE 7 /* build/lib/multiagent/scenarios/simple_reference.py: two moving, speaking agents,
+                                  one goal landmark per agent (goal_b)                                          */
 
 /* error codes */
 #define MPE_OK 0
@@ -120,7 +124,13 @@ typedef struct mpe_scenario_desc {
  * void pointers = the _f32 / _f64 suffix of the function called.  Which members a call reads or
  * writes is stated at each function; members it does not use may be NULL.
  *   act    [act_total][ld]   agent i owns rows [act_row0(i), act_row0(i)+act_dim(i)): 5 physical
- *                            entries, then dim_c comm entries when the agent is not silent
+ *                            entries when the agent is movable (environment.py:51-53,174), then dim_c
+ *                            comm entries when it is not silent (:61-63,198-206)
+ *   goal   [goal_rows][ld]   landmark indices: agent.goal_a of simple_adversary / simple_push (1 row),
+ *                            agent 0's goal_b of simple_speaker_listener (1 row), every agent's goal_b of
+ *                            simple_reference (n_agents rows); see mpe_goal_rows
+ *   comm   [A][dim_c][ld]    agent.state.c: written by every world step when not NULL; READ by
+ *                            mpe_observe of the two speaking stock scenarios (required there)
  *   lforce [A][2][ld]        agent.leader_force (core.py:156-192): written by every world step,
  *                            read by the HIER_PURSUIT observation; NOT touched by reset (like the
  *                            reference's reset_world).  Required when any forced_id >= 0.
@@ -153,10 +163,12 @@ int mpe_obs_dim(const mpe_scenario_desc *desc, int agent);
 int mpe_obs_row0(const mpe_scenario_desc *desc, int agent);
 int mpe_obs_total(const mpe_scenario_desc *desc);
 int mpe_info_width(const mpe_scenario_desc *desc);
-/* Action geometry: 5 (+ dim_c for non-silent agents) entries per agent (environment.py:42-76). */
+/* Action geometry: 5 entries for a movable agent + dim_c for a non-silent one (environment.py:42-76). */
 int mpe_act_dim(const mpe_scenario_desc *desc, int agent);
 int mpe_act_row0(const mpe_scenario_desc *desc, int agent);
 int mpe_act_total(const mpe_scenario_desc *desc);
+/* Rows of the goal buffer for this scenario (0: the scenario has no goal landmark). */
+int mpe_goal_rows(const mpe_scenario_desc *desc);
 
 /*
  * World.step for every env (core.py:124-140): MultiAgentEnv._set_action decode

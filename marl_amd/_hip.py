@@ -20,7 +20,9 @@ MPE_SIMPLE = 2
 MPE_SIMPLE_ADVERSARY = 3
 MPE_SIMPLE_PUSH = 4
 MPE_HIER_PURSUIT = 5
-GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH)
+MPE_SPEAKER_LISTENER = 6
+MPE_SIMPLE_REFERENCE = 7
+GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE)
 ABI_VERSION = 3
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
@@ -90,7 +92,7 @@ def _load():
     L.mpe_strerror.restype = C.c_char_p
     L.mpe_strerror.argtypes = [ci]
     bp = C.POINTER(Buffers)
-    for name in ('mpe_desc_check', 'mpe_obs_total', 'mpe_info_width', 'mpe_stats_width', 'mpe_act_total'):
+    for name in ('mpe_desc_check', 'mpe_obs_total', 'mpe_info_width', 'mpe_stats_width', 'mpe_act_total', 'mpe_goal_rows'):
         f = getattr(L, name)
         f.restype, f.argtypes = ci, [dp]
     for name in ('mpe_obs_dim', 'mpe_obs_row0', 'mpe_act_dim', 'mpe_act_row0'):

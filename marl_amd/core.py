@@ -222,10 +222,20 @@ class World(object):
         dtype = self.dtype if dtype is None else dtype
         return torch.zeros(*shape, self.ld, dtype=dtype, device=self.device)[..., :self.num_envs]
 
+    def set_goal_rows(self, n):
+        """Scenarios with one goal landmark per agent (simple_reference) keep ``world.goal`` as [n, B]."""
+        self.goal = self.rows(n, dtype=torch.int32)
+        self._buf.set(goal=self.goal)
+
     def new_action_buffer(self):
         """A tensor shaped and strided like ``world.act`` that MultiAgentEnv.step() adopts without a copy."""
         t = self.rows(sum(self.act_dims))
         return t.view(len(self.agents), 5, self.num_envs) if self.act.dim() == 3 else t
+
+    @property
+    def _uniform_actions(self):
+        """Every agent's action is exactly the 5 physical entries ([A, 5, B] layout)."""
+        return all(a.silent and a.movable for a in self.agents)
 
     def allocate(self, num_envs, device=None, dtype=torch.float64, ld=None):
         if device is None:
@@ -244,20 +254,21 @@ class World(object):
         self.vel = self.rows(A, 2)
         self.comm = self.rows(A, max(self.dim_c, 1))[:, :self.dim_c]
         # action rows (environment.py:42-76): 5 physical entries, + dim_c comm entries if not silent
-        self.act_dims = [5 + (0 if a.silent else self.dim_c) for a in self.agents]
+        self.act_dims = [(5 if a.movable else 0) + (0 if a.silent else self.dim_c) for a in self.agents]
         self.act_row0 = [sum(self.act_dims[:i]) for i in range(A)]
         self.act_rows = self.rows(sum(self.act_dims))
-        self.act = self.act_rows.view(A, 5, B) if all(a.silent for a in self.agents) else self.act_rows
+        self.act = self.act_rows.view(A, 5, B) if self._uniform_actions else self.act_rows
         self.lforce = self.rows(A, 2) if any(a.forced_id >= 0 for a in self.agents) else None
-        self.goal = self.rows(dtype=torch.int32)
+        self.goal = self.rows(dtype=torch.int32)   # [B]; [goal_rows, B] for scenarios with several goals (set_goal_rows)
         self.noise = None
         self._noise_buf = None
         self.obs = self.rew = self.info = self.obs_views = self.stats = None
         for i, e in enumerate(self.entities):
             e._world, e._index = self, i
         self._desc = None
-        self._buf = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal,
-                                 comm=self.comm if (self.dim_c and not all(a.silent for a in self.agents)) else None)
+        # agent.state.c is only maintained on device when somebody speaks
+        self._comm_arg = self.comm if (self.dim_c and not all(a.silent for a in self.agents)) else None
+        self._buf = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, comm=self._comm_arg)
         self.mark_dirty()
         return self
 
@@ -286,7 +297,8 @@ class World(object):
             return
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
-        b = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, obs=self.obs)
+        b = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, obs=self.obs,
+                         comm=self._comm_arg)
         _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_observe')
         self._obs_tick = self._tick
 

@@ -34,7 +34,8 @@ struct DevDesc {
   // fork's command hierarchy (core.py:153-194; L1F*/S1L* scenarios)
   int32_t has_lforce;      // some agent has forced_id >= 0
   int32_t reward_variant, n_target_obs;
-  int32_t act_row0[MPE_MAX_AGENTS];  // first action row of each agent (5 + dim_c rows if not silent)
+  int32_t act_row0[MPE_MAX_AGENTS];  // first action row of each agent (5 rows if movable, + dim_c if not silent)
+  int32_t cact_row0[MPE_MAX_AGENTS]; // first comm row inside the action (= act_row0 + 5 for a movable agent)
   uint32_t silent[MPE_MAX_AGENTS / 32];
   uint32_t advleader[MPE_MAX_AGENTS / 32];
   uint32_t advsuper[MPE_MAX_AGENTS / 32];
@@ -258,7 +259,7 @@ __device__ __forceinline__ void leader_force(const KParams<T> &p, int a, int64_t
   for (int l = 0; l < d.A; ++l) {
     if (d.force_id[l] != want) continue;
     const bool mute = bit(d.silent, l);  // action.c stays zeros(dim_c) (core.py:32-36)
-    const T *c = p.act + (int64_t)(d.act_row0[l] + 5) * p.ld + col;
+    const T *c = p.act + (int64_t)d.cact_row0[l] * p.ld + col;
     if (bit(d.advsuper, l)) {
       lfx = mute ? T(0) : ld_stream(c);
       lfy = mute ? T(0) : ld_stream(c + p.ld);
@@ -303,6 +304,10 @@ __device__ __forceinline__ T sqdist(T px, T py, T qx, T qy) {
 
 __device__ __forceinline__ bool kind_has_goal(int kind) {
   return kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH;
+}
+// the two speaking stock scenarios (per-agent goal_b + observed comm)
+__device__ __forceinline__ bool kind_is_comm(int kind) {
+  return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE;
 }
 
 // is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): strict <.

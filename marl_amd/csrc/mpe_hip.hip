@@ -31,6 +31,9 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
     const int nt = L < h->n_target_obs ? L : h->n_target_obs;
     return 4 + 4 * (A - 1) + (h->forced_id[i] >= 0 ? 2 : 0) + 2 * nt;
   }
+  if (h->kind == MPE_SPEAKER_LISTENER)  // simple_speaker_listener.py:89-94
+    return h->movable[i] ? 2 + 2 * L + h->dim_c * (A - 1) : 3;
+  if (h->kind == MPE_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + h->dim_c * (A - 1);  // simple_reference.py:89
   if (h->kind == MPE_SIMPLE) return 2 + 2 * L;  // simple.py:50
   if (h->kind == MPE_SIMPLE_ADVERSARY)          // simple_adversary.py:137-140
     return 2 * L + 2 * (A - 1) + (h->adversary[i] ? 0 : 2);
@@ -43,7 +46,16 @@ static bool kind_has_roles(int kind) {
   return kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH ||
          kind == MPE_HIER_PURSUIT;
 }
-static int act_dim_of(const mpe_scenario_desc *h, int i) { return 5 + (h->silent[i] ? 0 : h->dim_c); }
+static bool kind_is_comm(int kind) { return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE; }
+static bool kind_is_ragged(int kind) { return kind == MPE_HIER_PURSUIT || kind_is_comm(kind); }
+// environment.py:42-76: 5 physical entries for a movable agent, dim_c comm entries for a speaking one
+static int act_dim_of(const mpe_scenario_desc *h, int i) {
+  return (h->movable[i] ? 5 : 0) + (h->silent[i] ? 0 : h->dim_c);
+}
+static int goal_rows_of(const mpe_scenario_desc *h) {
+  if (h->kind == MPE_SIMPLE_ADVERSARY || h->kind == MPE_SIMPLE_PUSH || h->kind == MPE_SPEAKER_LISTENER) return 1;
+  return h->kind == MPE_SIMPLE_REFERENCE ? h->n_agents : 0;
+}
 static bool has_lforce(const mpe_scenario_desc *h) {
   for (int a = 0; a < h->n_agents; ++a)
     if (h->forced_id[a] >= 0) return true;
@@ -80,7 +92,7 @@ extern "C" const char *mpe_strerror(int code) {
 
 extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   if (!h) return MPE_ERR_NULL;
-  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_HIER_PURSUIT) return MPE_ERR_UNSUPPORTED;
+  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_SIMPLE_REFERENCE) return MPE_ERR_UNSUPPORTED;
   if (h->n_agents < 1 || h->n_agents > MPE_MAX_AGENTS) return MPE_ERR_DESC;
   if (h->n_landmarks < 0 || h->n_agents + h->n_landmarks > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
   if (h->dim_c < 0 || h->dim_c > 16) return MPE_ERR_DESC;
@@ -102,13 +114,23 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
     if (!(h->obs_r[a] >= 0.0) || !std::isfinite(h->obs_r[a])) return MPE_ERR_DESC;
     // comm entries are consumed by the command hierarchy only; the stock scenarios that observe
     // other.state.c (simple_spread.py:95) are built silent (simple_spread.py:17)
-    if (!h->silent[a] && h->kind != MPE_HIER_PURSUIT) return MPE_ERR_UNSUPPORTED;
+    if (!h->silent[a] && !kind_is_ragged(h->kind)) return MPE_ERR_UNSUPPORTED;
+    // an agent that neither moves nor speaks has no action at all (the reference cannot build its
+    // action space either, environment.py:76)
+    if (!h->movable[a] && h->silent[a]) return MPE_ERR_UNSUPPORTED;
     // a super-leader's command is c[0:2] (core.py:163)
     if (h->advsuperleader[a] && h->force_id[a] >= 0 && !h->silent[a] && h->dim_c < 2) return MPE_ERR_DESC;
   }
   if (h->kind == MPE_HIER_PURSUIT) {
     if (h->n_target_obs < 0 || h->n_target_obs > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
     if (h->reward_variant != 0 && h->reward_variant != 1) return MPE_ERR_DESC;
+  }
+  if (kind_is_comm(h->kind)) {
+    // two agents, three coloured landmarks (simple_speaker_listener.py:16,48-50 / simple_reference.py:11,41-43)
+    if (h->n_agents != 2 || h->n_landmarks != 3 || h->dim_c < 1) return MPE_ERR_DESC;
+    if (h->kind == MPE_SPEAKER_LISTENER &&
+        (h->movable[0] || h->silent[0] || !h->movable[1] || !h->silent[1]))  // speaker, then listener
+      return MPE_ERR_DESC;
   }
   if (h->kind == MPE_SIMPLE && h->n_landmarks < 1) return MPE_ERR_DESC;
   if (kind_has_goal(h->kind)) {  // a goal landmark and at least one good agent must exist
@@ -163,6 +185,11 @@ extern "C" int mpe_act_total(const mpe_scenario_desc *h) {
   for (int i = 0; i < h->n_agents; ++i) r += act_dim_of(h, i);
   return r;
 }
+extern "C" int mpe_goal_rows(const mpe_scenario_desc *h) {
+  int rc = mpe_desc_check(h);
+  if (rc) return rc;
+  return goal_rows_of(h);
+}
 extern "C" int mpe_info_width(const mpe_scenario_desc *h) {
   int rc = mpe_desc_check(h);
   if (rc) return rc;
@@ -211,6 +238,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     d.obs_row0[a] = row;
     row += obs_dim_of(h, a);
     d.act_row0[a] = arow;
+    d.cact_row0[a] = arow + (h->movable[a] ? 5 : 0);
     arow += act_dim_of(h, a);
     if (h->silent[a]) d.silent[a >> 5] |= 1u << (a & 31);
     if (h->advleader[a]) d.advleader[a >> 5] |= 1u << (a & 31);
@@ -311,7 +339,7 @@ template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   constexpr int TILE = tile_envs<T>();
   const size_t lds = tile_lds_bytes<T>(h, THREADS);
-  auto kern = h->kind == MPE_HIER_PURSUIT ? tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, true>
+  auto kern = kind_is_ragged(h->kind) ? tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, true>
                                           : tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, false>;
   if (lds > 64 * 1024) {
     if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
@@ -415,7 +443,8 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   if (do_step && !b->act) return MPE_ERR_NULL;
   const bool lf = has_lforce(h);
   if (lf && !b->lforce) return MPE_ERR_NULL;
-  if (do_obs && kind_has_goal(h->kind) && !b->goal) return MPE_ERR_NULL;
+  if (do_obs && goal_rows_of(h) > 0 && !b->goal) return MPE_ERR_NULL;
+  if (do_obs && !do_step && kind_is_comm(h->kind) && !b->comm) return MPE_ERR_NULL;  // observed agent.state.c
   p.pos = (T *)b->pos;
   p.vel = (T *)b->vel;
   p.lforce = lf ? (T *)b->lforce : nullptr;
@@ -425,6 +454,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
     p.comm = (T *)b->comm;
   }
   if (do_obs) {
+    if (!do_step) p.comm = (T *)b->comm;
     p.goal = b->goal;
     p.obs = (T *)b->obs;
     p.rew = (T *)b->rew;
@@ -473,7 +503,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E, int A, int dim_c, double ra,
                                                      double rl, uint32_t k0, uint32_t k1, uint32_t episode,
                                                      uint64_t env_id0, const uint8_t *mask, T *pos, T *vel,
-                                                     T *comm, int32_t *goal) {
+                                                     T *comm, int32_t *goal, int goal_rows) {
   const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (env >= B) return;
   if (mask != nullptr && mask[env] == 0) return;
@@ -481,7 +511,8 @@ __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E
   if (goal != nullptr) {  // goal = np.random.choice(world.landmarks) (simple_adversary.py:45)
     uint32_t w[4];
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), episode, 0xFFFFFFFFu, k0, k1, w);
-    goal[env] = (int32_t)(((uint64_t)w[0] * (uint64_t)(E - A)) >> 32);
+    for (int r = 0; r < goal_rows; ++r)  // one word per goal row (goal_rows <= 2 with the stock scenarios)
+      goal[(int64_t)r * ld + env] = (int32_t)(((uint64_t)w[r & 3] * (uint64_t)(E - A)) >> 32);
   }
   for (int e = 0; e < E; ++e) {
     uint32_t w[4];
@@ -505,12 +536,12 @@ static int reset_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_
   int32_t *goal = b->goal;
   if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm) || misaligned<int32_t>(goal))
     return MPE_ERR_ALIGN;
-  if (h->n_landmarks < 1) goal = nullptr;
+  if (h->n_landmarks < 1 || goal_rows_of(h) < 1) goal = nullptr;
   const dim3 grid((unsigned)((B + 255) / 256)), block(256);
   hipLaunchKernelGGL(reset_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld,
                      h->n_agents + h->n_landmarks, h->n_agents, h->dim_c, h->agent_pos_range,
                      h->landmark_pos_range, (uint32_t)seed, (uint32_t)(seed >> 32), episode, env_id0, mask, pos,
-                     vel, comm, goal);
+                     vel, comm, goal, goal_rows_of(h));
   return (int)hipGetLastError();
 }
 

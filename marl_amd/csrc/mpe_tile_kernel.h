@@ -24,8 +24,8 @@
 
 namespace mpe {
 
-// HIER: the world is a command hierarchy (kind MPE_HIER_PURSUIT; the only kind that may carry
-// force_id / forced_id / comm actions, mpe_hip.hip:mpe_desc_check).  A template flag so that the
+// HIER: the world may carry ragged actions / speaking agents (kinds MPE_HIER_PURSUIT, the only one with
+// force_id / forced_id, MPE_SPEAKER_LISTENER and MPE_SIMPLE_REFERENCE; mpe_hip.hip:mpe_desc_check).  A template flag so that the
 // stock kinds do not pay for its branches in the per-agent loops (scaled simple_tag: 3.80 -> 3.50 ms).
 template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           const bool mute = !HIER || bit(d.silent, a);
           for (int c = 0; c < d.dim_c; ++c)
             p.comm[(int64_t)(a * d.dim_c + c) * ld + env] =
-                mute ? T(0) : ld_stream(p.act + (int64_t)(d.act_row0[a] + 5 + c) * ld + env);
+                mute ? T(0) : ld_stream(p.act + (int64_t)(d.cact_row0[a] + c) * ld + env);
         }
       }
       __syncthreads();
@@ -187,6 +187,41 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+          if (HIER && kind_is_comm(d.kind)) {
+            // simple_speaker_listener.py:72-94 / simple_reference.py:62-89
+            const bool ref = d.kind == MPE_SIMPLE_REFERENCE;
+            int g = p.goal[(int64_t)(ref ? i : 0) * ld + ge];  // agent.goal_b
+            g = g < 0 ? 0 : (g >= L ? L - 1 : g);
+            const T base = ref ? T(0.25) : T(0.15), hi = ref ? T(0.75) : T(0.65);  // landmark.color tables
+            if (!ref && !bit(d.movable, i)) {  // the speaker sees the goal colour only
+              for (int k = 0; k < 3; ++k) { st_stream(o, k == g ? hi : base); o += ld; }
+              continue;
+            }
+            st_stream(o, sVel[(2 * i) * TILE + lane]);
+            st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+            o += 2 * ld;
+            for (int l = A; l < E; ++l) {
+              st_stream(o, sPos[(2 * l) * TILE + lane] - pix);
+              st_stream(o + ld, sPos[(2 * l + 1) * TILE + lane] - piy);
+              o += 2 * ld;
+            }
+            if (ref)
+              for (int k = 0; k < 3; ++k) { st_stream(o, k == g ? hi : base); o += ld; }
+            // other.state.c: what this step just set from the actions (core.py:226-230), or the comm
+            // buffer when only observing
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              for (int c = 0; c < d.dim_c; ++c) {
+                T v = T(0);
+                if (!bit(d.silent, j))
+                  v = DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[j] + c) * ld + env)
+                              : p.comm[(int64_t)(j * d.dim_c + c) * ld + env];
+                st_stream(o, v);
+                o += ld;
+              }
+            }
+            continue;
+          }
           if (HIER && d.kind == MPE_HIER_PURSUIT) {
             // L1F2_3Targets_100observe.py:198-253 (same text in every L1F*/S1L* file)
             st_stream(o, sVel[(2 * i) * TILE + lane]);
@@ -360,6 +395,26 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_t = group_sum(active ? (double)total : 0.0, TILE);
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        } else if (HIER && kind_is_comm(d.kind)) {
+          // simple_speaker_listener.py:66-70 (both agents: listener to agent 0's goal) /
+          // simple_reference.py:56-60 (agent i: the OTHER agent to agent i's goal)
+          const bool ref = d.kind == MPE_SIMPLE_REFERENCE;
+          for (int i = chunk; i < A; i += NCH) {
+            int g = p.goal[(int64_t)(ref ? i : 0) * ld + ge];
+            g = g < 0 ? 0 : (g >= L ? L - 1 : g);
+            const int who = ref ? 1 - i : 1;
+            const T r_i = -sqdist<T>(sPos[(2 * who) * TILE + lane], sPos[(2 * who + 1) * TILE + lane],
+                                     sPos[(2 * (A + g)) * TILE + lane], sPos[(2 * (A + g) + 1) * TILE + lane]);
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              if (lane == 0) srow[i] += s_r;
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) srow[2 * A + 1] += s_n;
           }
         } else if (HIER && d.kind == MPE_HIER_PURSUIT) {
           // n_o = number of targets agent o touches (is_collision, L1F2_3Targets_100observe.py:150-154)

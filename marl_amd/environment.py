@@ -57,23 +57,25 @@ class MultiAgentEnv(object):
         self._scenario = owners.pop() if len(owners) == 1 else None
         self._fused = (isinstance(self._scenario, HipScenario) and done_callback is None
                        and all(getattr(cb, '__func__', None) is getattr(HipScenario, nm)
-                               for cb, nm in ((reward_callback, 'reward'), (observation_callback, 'observation'))))
+                               for cb, nm in ((reward_callback, 'reward'), (observation_callback, 'observation')))
+                       and (info_callback is None
+                            or getattr(info_callback, '__func__', None) is HipScenario.benchmark_data))
 
         # configure spaces (environment.py:39-80)
         self.action_space = []
         self.observation_space = []
         for agent in self.agents:
-            if not agent.movable:
-                raise NotImplementedError('only movable agents are on the HIP hot path')
             u_space = spaces.Discrete(world.dim_p * 2 + 1)
-            if agent.silent:
-                self.action_space.append(u_space)
-            else:                                     # environment.py:61-69
-                self.action_space.append(spaces.MultiDiscrete([[0, u_space.n - 1], [0, world.dim_c - 1]]))
+            c_space = spaces.Discrete(world.dim_c)
+            total = ([u_space] if agent.movable else []) + ([] if agent.silent else [c_space])   # environment.py:43-63
+            if len(total) > 1:                        # environment.py:65-73
+                self.action_space.append(spaces.MultiDiscrete([[0, sp.n - 1] for sp in total]))
+            else:
+                self.action_space.append(total[0])    # IndexError for an agent with no action, like the reference
             obs_dim = int(observation_callback(agent, self.world).shape[-1])
             self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf, shape=(obs_dim,), dtype=np.float32))
         self._own_act = world.act
-        self._uniform = all(agent.silent for agent in self.agents)          # world.act is [n,5,B]
+        self._uniform = world._uniform_actions                              # world.act is [n,5,B]
         self.action_views = [world.act_rows[r0:r0 + n].t()                  # [B,act_dim] views, strides (1,B)
                              for r0, n in zip(world.act_row0, world.act_dims)]
         self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=world.device)

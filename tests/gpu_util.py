@@ -31,7 +31,7 @@ class HipSim:
         self.obs = torch.full((sum(spec.obs_dims), self.ld), float('nan'), **z)
         self.rew = torch.full((A, self.ld), float('nan'), **z)
         self.info = torch.full((A, spec.info_width, self.ld), float('nan'), **z)
-        self.goal = torch.zeros(self.ld, dtype=torch.int32, device='cuda')
+        self.goal = torch.zeros(max(spec.goal_rows, 1), self.ld, dtype=torch.int32, device='cuda')
         self.lforce = torch.zeros(A, 2, self.ld, **z) if spec.has_leader_force else None
         self.comm = torch.full((A, max(spec.dim_c, 1), self.ld), float('nan'), **z)[:, :spec.dim_c]
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -40,7 +40,7 @@ class HipSim:
         self.pos[:, :, :self.B] = dev(pos, self.dtype)
         self.vel[:, :, :self.B] = dev(vel, self.dtype)
         if goal is not None:
-            self.goal[:self.B] = torch.as_tensor(np.maximum(np.asarray(goal), 0), dtype=torch.int32).cuda()
+            self.goal[:, :self.B] = torch.as_tensor(np.maximum(np.asarray(goal), 0), dtype=torch.int32).cuda().reshape(-1, self.B)
         if lforce is not None:
             self.lforce[:, :, :self.B] = dev(lforce, self.dtype)
 
@@ -64,8 +64,8 @@ class HipSim:
         rc = getattr(lib, 'mpe_world_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
-    def observe(self, obs=True, rew=True, info=True):
-        b = self.buffers(obs=self.obs if obs else None, rew=self.rew if rew else None,
+    def observe(self, obs=True, rew=True, info=True, comm=None):
+        b = self.buffers(comm=comm, obs=self.obs if obs else None, rew=self.rew if rew else None,
                          info=self.info if (info and self.info.numel()) else None)
         rc = getattr(lib, 'mpe_observe_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)

@@ -320,3 +320,48 @@ def test_training_loop_with_target_move_and_benchmark_reset():
         assert torch.equal(w.agents[i].state.p_pos, want[i].expand(B, 2)) and (w.agents[i].state.p_vel == 0).all()
         assert torch.equal(obs_n[i][:, 2:4], want[i].expand(B, 2))
     assert torch.equal(w.pos[3:], lm)                                     # landmarks keep their positions
+
+
+@pytest.mark.parametrize('name,mk', [('simple_speaker_listener', O.speaker_listener_spec), ('simple_reference', O.simple_reference_spec)])
+def test_speaking_scenarios_episode_loop_matches_oracle(name, mk):
+    """SURVEY 8f row f1 (speaking half) through the public API: action spaces as the reference builds
+    them (environment.py:42-76), reset (Philox positions + goals), 25 steps against the oracle (f64)."""
+    from marl_amd import make_env, spaces
+    spec = mk()
+    B, T = 320, 25
+    env = make_env(name, num_envs=B, dtype=torch.float64, seed=9)
+    want_spaces = {'simple_speaker_listener': [spaces.Discrete(3), spaces.Discrete(5)],
+                   'simple_reference': [spaces.MultiDiscrete([[0, 4], [0, 9]])] * 2}[name]
+    assert env.action_space == want_spaces
+    assert [s.shape[0] for s in env.observation_space] == spec.obs_dims
+    obs_n = env.reset()
+    w = env.world
+    ids = np.arange(B, dtype=np.uint64)
+    assert np.array_equal(w.pos.cpu().numpy(), O.reset_positions(spec, 9, w.episode - 1, ids))
+    goal = w.goal.cpu().numpy().reshape(spec.goal_rows, B)
+    assert np.array_equal(goal, O.reset_goals(spec, 9, w.episode - 1, ids).reshape(spec.goal_rows, B))
+    bo = O.BatchedOracle(spec)
+    pos, vel = _np(w.pos), _np(w.vel)
+    obs0, _, _ = bo.observe(pos, vel, goal=goal)
+    for i in range(env.n):
+        assert np.array_equal(_np(obs_n[i]).T, obs0[i])
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    for t in range(T):
+        action_n = [torch.rand(B, d, generator=gen, device='cuda', dtype=torch.float64) for d in spec.act_dims]
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        act = np.concatenate([_np(a).T for a in action_n], 0)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, goal=goal)
+        np.testing.assert_allclose(_np(w.pos), pos, rtol=0, atol=1e-9)
+        for i, a in enumerate(w.agents):
+            np.testing.assert_allclose(_np(new_obs_n[i]).T, obs[i], rtol=0, atol=1e-9)
+            assert np.array_equal(_np(a.state.c).T, bo.comm_state(act)[i])
+        np.testing.assert_allclose(np.stack([_np(x) for x in rew_n]), rew, rtol=0, atol=1e-9)
+        assert info_n == {'n': [{}] * env.n}
+    if name == 'simple_reference':                                        # no benchmark_data attribute at all
+        with pytest.raises(AttributeError):
+            make_env(name, benchmark=True, num_envs=4)
+    else:                                                                 # defined but broken: fails when called (:62-64)
+        env = make_env(name, benchmark=True, num_envs=4)
+        env.reset()
+        with pytest.raises(NameError):
+            env.step([torch.rand(4, d, device='cuda', dtype=torch.float64) for d in spec.act_dims])

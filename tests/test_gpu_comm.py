@@ -1,0 +1,112 @@
+"""GPU parity for the speaking stock scenarios of SURVEY 8f row f1: simple_speaker_listener and
+simple_reference (ragged actions, agent.state.c observed by the other agent, per-agent goal_b)
+through the C ABI, against the golden vectors generated from the reference and the CPU oracle.
+f64 <= 1e-9 over free-running 25-step episodes; f32 <= 1e-4 (no thresholds in these scenarios)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tests.gpu_util import HipSim, dev, golden_soa, lib
+
+CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec)]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _maxerr(got, want):
+    return float(np.max(np.abs(got - want))) if got.size else 0.0
+
+
+@pytest.mark.parametrize('name,mk', CASES)
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=['f64', 'f32'])
+def test_trajectory_matches_reference(golden_dir, name, mk, dtype, tol):
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    goal = np.maximum(g['goal'].T[:spec.goal_rows], 0)
+    sim = HipSim(spec, S, dtype)
+    sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'), goal)
+    sim.comm[:, :, :S] = dev(golden_soa(g, 'comm0'), dtype)
+    sim.observe(rew=False, info=False, comm=sim.comm)
+    assert _maxerr(sim.host()[2], g['obs0'].T) <= (0.0 if dtype == torch.float64 else tol)
+    worst = 0.0
+    for t in range(T):
+        if dtype == torch.float32 and t:                                  # teacher-forced
+            sim.set_state(golden_soa(g, 'pos', t - 1), golden_soa(g, 'vel', t - 1), goal)
+        sim.env_step(dev(g['act'][:, t].T, dtype), comm=sim.comm)
+        pos, vel, obs, rew, info = sim.host()
+        errs = (_maxerr(pos, golden_soa(g, 'pos', t)), _maxerr(vel, golden_soa(g, 'vel', t)),
+                _maxerr(sim.comm[..., :S].double().cpu().numpy(), golden_soa(g, 'comm', t)),
+                _maxerr(obs, g['obs'][:, t].T))
+        rerr = np.abs(rew - golden_soa(g, 'rew', t)) / np.maximum(1.0, np.abs(golden_soa(g, 'rew', t)))
+        worst = max(worst, *errs, float(rerr.max()))
+        assert max(errs) <= tol and rerr.max() <= tol, (name, t, errs, rerr.max())
+    print('%s %s worst |err| = %.3e' % (name, dtype, worst))
+
+
+@pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtype):
+    """mpe_world_step + mpe_observe (which reads agent.state.c from the comm buffer) == mpe_env_step
+    (which reads it from the actions), bit for bit, on a ragged batch with ld > B; f64 also against
+    the batched oracle; statistics rows hold the reward sums."""
+    spec = mk()
+    B, ld, steps = 5000 + 19, 5120, 3
+    rng = np.random.RandomState(5)
+    pos = rng.uniform(-1, 1, (spec.n_entities, 2, B))
+    vel = rng.uniform(-0.5, 0.5, (spec.n_agents, 2, B))
+    goal = rng.randint(0, 3, (spec.goal_rows, B))
+    a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
+    a.set_state(pos, vel, goal)
+    b.set_state(pos, vel, goal)
+    rows, width = lib.mpe_stats_rows(a.desc, B, 8 if dtype == torch.float64 else 4), lib.mpe_stats_width(a.desc)
+    stats = torch.zeros(rows, width, dtype=torch.float64, device='cuda')
+    bo = O.BatchedOracle(spec)
+    want_sum = np.zeros(spec.n_agents)
+    for t in range(steps):
+        an = rng.rand(sum(spec.act_dims), B)
+        act = torch.zeros(sum(spec.act_dims), ld, dtype=dtype, device='cuda')
+        act[:, :B] = dev(an, dtype)
+        a.env_step(act, comm=a.comm, stats=stats)
+        b.world_step(act, comm=b.comm)
+        b.observe(comm=b.comm)
+        for x, y in zip(a.host(), b.host()):
+            assert np.array_equal(x, y, equal_nan=True)
+        assert torch.equal(a.comm[..., :B], b.comm[..., :B])
+        if dtype == torch.float64:
+            pos, vel, obs, rew, info = bo.env_step(pos, vel, an, goal=goal)
+            gp, gv, go, gr, gi = a.host()
+            assert max(_maxerr(gp, pos), _maxerr(gv, vel), _maxerr(go, np.concatenate(obs, 0)), _maxerr(gr, rew)) <= 1e-9
+            assert _maxerr(a.comm[..., :B].cpu().numpy(), bo.comm_state(an)) == 0.0
+            want_sum += rew.sum(1)
+    for t_ in (a.obs, a.rew):
+        assert torch.isnan(t_[..., B:]).all()                              # padding never written
+    assert torch.isnan(a.comm[..., B:]).all()
+    if dtype == torch.float64:
+        out = torch.empty(width, dtype=torch.float64, device='cuda')
+        assert lib.mpe_stats_reduce(stats.data_ptr(), rows, width, out.data_ptr(), a.stream) == 0
+        np.testing.assert_allclose(out.cpu().numpy()[:spec.n_agents], want_sum, rtol=1e-9)
+        assert out[2 * spec.n_agents + 1].item() == steps * B
+
+
+@pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
+def test_reset_draws_goals_from_the_philox_oracle(mk):
+    spec = mk()
+    B = 2048
+    sim = HipSim(spec, B, torch.float64)
+    sim.reset(seed=11, episode=4, env_id0=100)
+    ids = np.arange(B, dtype=np.uint64) + 100
+    assert np.array_equal(sim.goal[:spec.goal_rows].cpu().numpy().reshape(spec.goal_rows, B),
+                          O.reset_goals(spec, 11, 4, ids).reshape(spec.goal_rows, B))
+    assert np.array_equal(sim.pos.cpu().numpy(), O.reset_positions(spec, 11, 4, ids))
+    g = sim.goal[:spec.goal_rows].cpu().numpy()
+    assert g.min() == 0 and g.max() == 2 and (spec.goal_rows == 1 or (g[0] != g[1]).mean() > 0.5)

@@ -306,7 +306,7 @@ def test_reset_matches_philox_oracle(dtype, force_tile):
     ga = HipSim(adv, 3000, dtype)
     ga.reset(seed=99, episode=2, env_id0=17)
     want_goal = O.reset_goals(adv, 99, 2, np.arange(3000, dtype=np.uint64) + np.uint64(17))
-    assert np.array_equal(ga.goal.cpu().numpy(), want_goal)
+    assert np.array_equal(ga.goal[0].cpu().numpy(), want_goal)
     assert set(np.unique(want_goal)) == {0, 1, 2, 3}
     # mask
     before = sim.pos.clone()

@@ -203,3 +203,34 @@ def test_shard_range_partitions_the_batch():
         for (s0, c0), (s1, _) in zip(spans, spans[1:]):
             assert s0 + c0 == s1
         assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_comm_scenarios_geometry_and_validation():
+    """simple_speaker_listener / simple_reference: ragged action rows (a fixed speaker has no physical
+    entries), goal rows, and the descriptor checks that pin the stock roles."""
+    from marl_amd import _hip, spaces
+    import marl_amd.scenarios as scenarios
+    lib = _hip.lib
+    for spec in (O.speaker_listener_spec(), O.simple_reference_spec()):
+        d = _desc(spec)
+        assert [lib.mpe_act_dim(d, i) for i in range(2)] == spec.act_dims
+        assert lib.mpe_act_total(d) == sum(spec.act_dims) and lib.mpe_goal_rows(d) == spec.goal_rows
+        assert [lib.mpe_obs_dim(d, i) for i in range(2)] == spec.obs_dims and lib.mpe_info_width(d) == 0
+    assert O.speaker_listener_spec().act_dims == [3, 5] and O.simple_reference_spec().act_dims == [15, 15]
+    assert lib.mpe_goal_rows(_desc(O.simple_tag_spec())) == 0 and lib.mpe_goal_rows(_desc(O.simple_push_spec())) == 1
+    d = _desc(O.speaker_listener_spec())
+    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.movable[0] = 1
+    assert lib.mpe_desc_check(bad) == -2                      # the speaker does not move
+    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.n_landmarks = 4
+    assert lib.mpe_desc_check(bad) == -2                      # three coloured landmarks
+    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.silent[0] = 1
+    assert lib.mpe_desc_check(bad) == -5                      # an agent with no action at all
+    b = _hip.Buffers()
+    b.pos, b.vel, b.obs, b.goal = 8, 8, 8, 8
+    assert lib.mpe_observe_f64(d, 4, 4, b, None) == -1        # observing needs agent.state.c (comm)
+    for name, kind in (('simple_speaker_listener', _hip.MPE_SPEAKER_LISTENER), ('simple_reference', _hip.MPE_SIMPLE_REFERENCE)):
+        sc = scenarios.load(name + '.py').Scenario()
+        sc._finish_world = lambda world: world
+        w = sc.make_world()
+        spec = O.speaker_listener_spec() if kind == _hip.MPE_SPEAKER_LISTENER else O.simple_reference_spec()
+        assert bytes(w.descriptor()) == bytes(_desc(spec))
