@@ -44,6 +44,9 @@ WORKLOADS = {
     'L1F2_3Targets_1M_f32': ('L1F2_3Targets_100observe', {}, 1 << 20, torch.float32),
     'S1L2F2_10Targets_1M_f32': ('S1L2F2_10Targets_wide', {}, 1 << 20, torch.float32),
     'S1L2F2_10Targets_1M_f64': ('S1L2F2_10Targets_wide', {}, 1 << 20, torch.float64),
+    # SURVEY 8f row f1, the speaking stock scenarios
+    'simple_speaker_listener_2M_f32': ('simple_speaker_listener', {}, 1 << 21, torch.float32),
+    'simple_reference_1M_f32': ('simple_reference', {}, 1 << 20, torch.float32),
 }
 
 
@@ -57,7 +60,8 @@ def algorithmic_elems(env, with_info=True):
     info_w = w.info.shape[1] if (with_info and w.info is not None and env.info_callback is not None) else 0
     # agent.state.c of every agent is rewritten each step once any agent speaks (core.py:224-230)
     extra = (2 * A if w.lforce is not None else 0) + (A * w.dim_c if any(not a.silent for a in w.agents) else 0)
-    return sum(w.act_dims) + 2 * E + 2 * A + 4 * A + obs + A + A * info_w + extra
+    moving = sum(1 for a in w.agents if a.movable)           # only movable agents have / update a velocity
+    return sum(w.act_dims) + 2 * E + 2 * moving + 4 * moving + obs + A + A * info_w + extra
 
 
 def measured_traffic(workload):
@@ -143,7 +147,8 @@ def main():
     scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[args.workload]
     B = args.envs or envs_per_gpu
     env_id0, _ = shard_range(B * world_size, rank, world_size)      # weak scaling: B per GPU fixed
-    has_info = scenario not in ('simple', 'simple_push')       # those define no benchmark_data
+    # scenarios without a (working) benchmark_data
+    has_info = scenario not in ('simple', 'simple_push', 'simple_speaker_listener', 'simple_reference')
     env = make_env(scenario, benchmark=has_info, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
     env.world.env_id0 = env_id0
     n = env.n
@@ -157,8 +162,9 @@ def main():
         if w.act.dim() == 3:
             a.copy_(torch.softmax(torch.randn(n, 5, B, generator=gen, device=device, dtype=dtype), dim=1))
             return a
-        for r0, d in zip(w.act_row0, w.act_dims):
-            for lo, hi in ((r0, r0 + 5), (r0 + 5, r0 + d)):
+        for ag, r0, d in zip(w.agents, w.act_row0, w.act_dims):
+            nu = 5 if ag.movable else 0                      # physical part, then the comm part
+            for lo, hi in ((r0, r0 + nu), (r0 + nu, r0 + d)):
                 if hi > lo:
                     a[lo:hi] = torch.softmax(torch.randn(hi - lo, B, generator=gen, device=device, dtype=dtype), dim=0)
         return a

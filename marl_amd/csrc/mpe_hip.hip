@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "mpe_device.h"
+#include "mpe_comm_kernel.h"
 #include "mpe_hier_kernel.h"
 #include "mpe_small_kernel.h"
 #include "mpe_tile_kernel.h"
@@ -269,8 +270,24 @@ enum SmallId {
   HIER_3_10_1,              // S1L1F1_10Targets_wide
   HIER_5_3_2,               // S1L2F2_3Targets_*
   HIER_5_10_2,              // S1L2F2_10Targets_wide(_rewardFixed)
-  HIER_LAST = HIER_5_10_2
+  HIER_LAST = HIER_5_10_2,
+  // speaking stock scenarios (mpe_comm_kernel.h)
+  COMM_SPEAKER_LISTENER,
+  COMM_REFERENCE
 };
+
+// Stock shape of simple_speaker_listener / simple_reference (mpe_comm_kernel.h header), or SMALL_NONE.
+static SmallId comm_variant(const mpe_scenario_desc *h) {
+  const bool ref = h->kind == MPE_SIMPLE_REFERENCE;
+  if (h->dim_c != (ref ? 10 : 3)) return SMALL_NONE;
+  for (int e = 0; e < h->n_agents + h->n_landmarks; ++e)
+    if (h->collide[e]) return SMALL_NONE;
+  for (int a = 0; a < h->n_agents; ++a) {
+    if (h->max_speed[a] >= 0.0 || h->u_noise[a] != 0.0) return SMALL_NONE;
+    if (ref && (!h->movable[a] || h->silent[a])) return SMALL_NONE;  // speaker_listener roles: mpe_desc_check
+  }
+  return ref ? COMM_REFERENCE : COMM_SPEAKER_LISTENER;
+}
 
 // Stock shape of a command-hierarchy world (mpe_hier_kernel.h header), or SMALL_NONE.
 static SmallId hier_variant(const mpe_scenario_desc *h) {
@@ -307,6 +324,8 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
     case MPE_SIMPLE_ADVERSARY: id = SMALL_ADVERSARY_3_2; if (A != 3 || L != 2) return SMALL_NONE; nadv = 1; ecol = 0; has_max = false; break;
     case MPE_SIMPLE_PUSH: id = SMALL_PUSH_10_1; if (A != 10 || L != 1) return SMALL_NONE; nadv = 9; ecol = 10; has_max = false; break;
     case MPE_HIER_PURSUIT: return hier_variant(h);
+    case MPE_SPEAKER_LISTENER:
+    case MPE_SIMPLE_REFERENCE: return comm_variant(h);
     default: return SMALL_NONE;
   }
   for (int a = 0; a < A; ++a) {
@@ -368,6 +387,13 @@ static int launch_hier(const KParams<T> &p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <typename T, int KIND, int C, bool DO_STEP, bool DO_OBS>
+static int launch_comm(const KParams<T> &p, hipStream_t s) {
+  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+  hipLaunchKernelGGL((comm_kernel<T, KIND, C, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) {
   if constexpr (THREADS == kSmallThreads) {
@@ -379,6 +405,8 @@ static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStrea
       case HIER_3_10_1: return launch_hier<T, 3, 10, 1, DO_STEP, DO_OBS>(p, s);
       case HIER_5_3_2: return launch_hier<T, 5, 3, 2, DO_STEP, DO_OBS>(p, s);
       case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
+      case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
+      case COMM_REFERENCE: return launch_comm<T, MPE_SIMPLE_REFERENCE, 10, DO_STEP, DO_OBS>(p, s);
       default: break;
     }
   }

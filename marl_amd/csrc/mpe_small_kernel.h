@@ -213,7 +213,8 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
           const double s_r = group_sum(active ? (double)rew[i] : 0.0, 64);
           if (lane == 0) sred1[wave][i] = s_r;
         }
-        if (lane == 0) sred1[wave][A] = (double)__builtin_popcountll(__ballot(active));
+        const double n_active = (double)__builtin_popcountll(__ballot(active));  // all lanes vote
+        if (lane == 0) sred1[wave][A] = n_active;
         __syncthreads();
         if (threadIdx.x <= A) {
           double s = 0.0;

@@ -26,9 +26,44 @@ def _maxerr(got, want):
     return float(np.max(np.abs(got - want))) if got.size else 0.0
 
 
+@pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
+def force_tile(request):
+    """The stock shapes run the register kernel (mpe_comm_kernel.h); the hook routes them through the
+    generic LDS-tile kernel too."""
+    lib.mpe_debug_force_tile_kernel(request.param)
+    yield request.param
+    lib.mpe_debug_force_tile_kernel(0)
+
+
+@pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
+def test_register_and_tile_kernels_bit_identical(mk):
+    spec = mk()
+    B = 4096 + 11
+    rng = np.random.RandomState(8)
+    pos = rng.uniform(-1, 1, (spec.n_entities, 2, B))
+    vel = rng.uniform(-0.5, 0.5, (spec.n_agents, 2, B))
+    goal = rng.randint(0, 3, (spec.goal_rows, B))
+    acts = rng.rand(4, sum(spec.act_dims), B)
+    for dtype in (torch.float64, torch.float32):
+        res = []
+        for ft in (0, 1):
+            lib.mpe_debug_force_tile_kernel(ft)
+            sim = HipSim(spec, B, dtype)
+            sim.set_state(pos, vel, goal)
+            sim.comm[:] = 0.25
+            sim.observe(comm=sim.comm)
+            out = [t.copy() for t in sim.host()]
+            for t in range(4):
+                sim.env_step(dev(acts[t], dtype), comm=sim.comm)
+            res.append(out + list(sim.host()) + [sim.comm.cpu().numpy()])
+        lib.mpe_debug_force_tile_kernel(0)
+        for x, y in zip(*res):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize('name,mk', CASES)
 @pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=['f64', 'f32'])
-def test_trajectory_matches_reference(golden_dir, name, mk, dtype, tol):
+def test_trajectory_matches_reference(golden_dir, name, mk, dtype, tol, force_tile):
     g = _load(golden_dir, name)
     spec = mk()
     S, T = g['act'].shape[:2]
@@ -55,7 +90,7 @@ def test_trajectory_matches_reference(golden_dir, name, mk, dtype, tol):
 
 @pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
-def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtype):
+def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtype, force_tile):
     """mpe_world_step + mpe_observe (which reads agent.state.c from the comm buffer) == mpe_env_step
     (which reads it from the actions), bit for bit, on a ragged batch with ld > B; f64 also against
     the batched oracle; statistics rows hold the reward sums."""

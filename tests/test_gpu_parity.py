@@ -388,3 +388,26 @@ def test_c_abi_rejects_bad_arguments():
     d.movable[5] = 1
     assert f(d, 8, 8, sim.buffers(**good), sim.stream) == -5
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('mk', [lambda: O.simple_spec(), lambda: O.simple_adversary_spec(), lambda: O.simple_push_spec()],
+                         ids=['simple', 'adversary', 'push'])
+def test_episode_stats_of_the_goal_scenarios(mk, force_tile):
+    """Statistics rows of simple / simple_adversary / simple_push: reward sums per agent and the env-step
+    count (the count once came out as one per wavefront: a ballot evaluated under `if (lane == 0)`)."""
+    spec = mk()
+    A, B = spec.n_agents, 3000 + 13
+    rng = np.random.RandomState(12)
+    sim = HipSim(spec, B, torch.float32)
+    sim.set_state(rng.uniform(-0.5, 0.5, (spec.n_entities, 2, B)), np.zeros((A, 2, B)),
+                  rng.randint(0, spec.n_landmarks, B))
+    rows, W = lib.mpe_stats_rows(sim.desc, B, 4), lib.mpe_stats_width(sim.desc)
+    stats = torch.zeros(rows, W, dtype=torch.float64, device='cuda')
+    want = torch.zeros(A, dtype=torch.float64, device='cuda')
+    for t in range(4):
+        sim.env_step(dev(rng.rand(A, 5, B), torch.float32), stats=stats)
+        want += sim.rew[:, :B].double().sum(1)
+    out = torch.empty(W, dtype=torch.float64, device='cuda')
+    assert lib.mpe_stats_reduce(stats.data_ptr(), rows, W, out.data_ptr(), sim.stream) == 0
+    torch.testing.assert_close(out[:A], want, rtol=1e-12, atol=1e-9)
+    assert out[2 * A + 1].item() == 4 * B
