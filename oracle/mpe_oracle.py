@@ -40,6 +40,7 @@ SIMPLE_PUSH = 4        # build/lib/multiagent/scenarios/simple_push.py
 HIER_PURSUIT = 5       # multiagent/scenarios/{L1F*,S1L*}.py: the fork's leader/follower pursuit
 SPEAKER_LISTENER = 6   # build/lib/multiagent/scenarios/simple_speaker_listener.py  (comm half)
 SIMPLE_REFERENCE = 7   # build/lib/multiagent/scenarios/simple_reference.py
+SIMPLE_CRYPTO = 8      # build/lib/multiagent/scenarios/simple_crypto.py (nobody moves: messages only)
 COMM_KINDS = (SPEAKER_LISTENER, SIMPLE_REFERENCE)   # per-agent goal landmark (agent.goal_b) + observed comm
 # landmark.color tables (simple_speaker_listener.py:48-50 / simple_reference.py:41-43): (base, highlighted)
 COMM_COLORS = {SPEAKER_LISTENER: (0.15, 0.65), SIMPLE_REFERENCE: (0.25, 0.75)}
@@ -112,6 +113,8 @@ class ScenarioSpec:
         agent 0's goal_b of simple_speaker_listener (1), every agent's goal_b of simple_reference (A)."""
         if self.kind in GOAL_KINDS or self.kind == SPEAKER_LISTENER:
             return 1
+        if self.kind == SIMPLE_CRYPTO:          # (goal_a landmark, landmark whose colour is the speaker's key)
+            return 2
         return self.n_agents if self.kind == SIMPLE_REFERENCE else 0
 
     @property
@@ -137,6 +140,8 @@ class ScenarioSpec:
             return 3 if not self.movable[i] else 2 + 2 * L + self.dim_c * (A - 1)
         if self.kind == SIMPLE_REFERENCE:       # simple_reference.py:89
             return 2 + 2 * L + 3 + self.dim_c * (A - 1)
+        if self.kind == SIMPLE_CRYPTO:          # simple_crypto.py:153-171: adversary / listener / speaker
+            return self.dim_c if self.adversary[i] else 2 * self.dim_c
         if self.kind == SIMPLE:                 # simple.py:50
             return 2 + 2 * L
         if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:137-140
@@ -153,6 +158,8 @@ class ScenarioSpec:
     def info_width(self):
         if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:58-67 (tuple of L+1 for good agents)
             return self.n_landmarks + 1
+        if self.kind == SIMPLE_CRYPTO:          # (agent.state.c, agent.goal_a.color), simple_crypto.py:78-80
+            return 2 * self.dim_c
         if self.kind in (SIMPLE, SIMPLE_PUSH) + COMM_KINDS:  # no (working) benchmark_data in these scenarios
             return 0
         return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT) else 4
@@ -219,6 +226,15 @@ def simple_reference_spec():
         size=[0.05] * 5, accel=[None, None], max_speed=[None, None],
         collide=[False] * 5, movable=[True, True, False, False, False], u_noise=[None, None], mass=[1.0] * 5,
         agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=10, silent=[False, False])
+
+
+def simple_crypto_spec():
+    """simple_crypto.py:21-44: adversary (Eve), listener (Bob), speaker (Alice); nobody moves, all speak."""
+    return ScenarioSpec(
+        kind=SIMPLE_CRYPTO, n_agents=3, n_landmarks=2, adversary=[True, False, False],
+        size=[0.05] * 5, accel=[None] * 3, max_speed=[None] * 3, collide=[False] * 5, movable=[False] * 5,
+        u_noise=[None] * 3, mass=[1.0] * 5, agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=4,
+        silent=[False] * 3)
 
 
 def simple_spec():
@@ -310,6 +326,8 @@ class SerialEnv:
         s = self.spec
         if s.kind in GOAL_KINDS:   # goal = np.random.choice(world.landmarks) (simple_adversary.py:45)
             self.goal = int(np.random.choice(len(self.landmarks)))
+        if s.kind == SIMPLE_CRYPTO:      # simple_crypto.py:61,63: goal, then the key
+            self.goals = [int(np.random.choice(len(self.landmarks))), int(np.random.choice(len(self.landmarks))), 0]
         if s.kind == SPEAKER_LISTENER:   # simple_speaker_listener.py:43
             self.goals[0] = int(np.random.choice(len(self.landmarks)))
         if s.kind == SIMPLE_REFERENCE:   # simple_reference.py:34,36
@@ -515,6 +533,15 @@ class SerialEnv:
         kind = self.spec.kind
         if kind == HIER_PURSUIT:
             return self._hier_observation(i)
+        if kind == SIMPLE_CRYPTO:                                # simple_crypto.py:124-171
+            onehot = lambda k: np.eye(self.spec.dim_c)[k]        # landmark.color = one-hot (:55-59)
+            goal_color, key = onehot(self.goals[0]), onehot(self.goals[1])
+            comm = [self.agents[2].comm] if i != 2 else []       # only the speaker's (agent 2) message is observed
+            if i == 2:
+                return np.concatenate([goal_color] + [key])
+            if not me.adversary:
+                return np.concatenate([key] + comm)
+            return np.concatenate(comm)
         if kind in COMM_KINDS:
             base, hi = COMM_COLORS[kind]
             color = np.full(3, base)
@@ -558,6 +585,21 @@ class SerialEnv:
         kind = self.spec.kind
         if kind == HIER_PURSUIT:
             return self._hier_reward(i)
+        if kind == SIMPLE_CRYPTO:                                # simple_crypto.py:94-121
+            goal_color = np.eye(self.spec.dim_c)[self.goals[0]]
+            zero = np.zeros(self.spec.dim_c)
+            if me.adversary:
+                rew = 0
+                if not (me.comm == zero).all():
+                    rew -= np.sum(np.square(me.comm - goal_color))
+                return rew
+            good_rew, adv_rew = 0, 0
+            bob, eve = self.agents[1], self.agents[0]
+            if not (bob.comm == zero).all():
+                good_rew -= np.sum(np.square(bob.comm - goal_color))
+            if not (eve.comm == zero).all():
+                adv_rew += np.sum(np.square(eve.comm - goal_color))
+            return adv_rew + good_rew
         if kind == SPEAKER_LISTENER:                             # simple_speaker_listener.py:66-70
             return -self._sq(self.agents[1], self.landmarks[self.goals[0]])
         if kind == SIMPLE_REFERENCE:                             # simple_reference.py:56-60 (goal_a = the other agent)
@@ -617,6 +659,8 @@ class SerialEnv:
         me = self.agents[i]
         if self.spec.kind == HIER_PURSUIT:
             return self._hier_info(i)
+        if self.spec.kind == SIMPLE_CRYPTO:                      # simple_crypto.py:78-80
+            return np.concatenate([me.comm, np.eye(self.spec.dim_c)[self.goals[0]]])
         if self.spec.kind == SIMPLE_ADVERSARY:                   # simple_adversary.py:58-67
             goal = self.landmarks[self.goal]
             if me.adversary:
@@ -817,6 +861,26 @@ class BatchedOracle:
             obs.append(np.concatenate(rows, axis=0))
         return obs, rew, np.zeros((A, 0, B), T)
 
+    def _observe_crypto(self, goal, comm):
+        """simple_crypto.py:78-171.  goal: [2, B] = (goal landmark, key landmark); comm: agent.state.c [3, dim_c, B]."""
+        s, T = self.spec, self.dt
+        C = s.dim_c
+        goal = np.asarray(goal, np.int64).reshape(2, -1)
+        B = goal.shape[1]
+        comm = np.zeros((3, C, B), T) if comm is None else np.asarray(comm, T)
+        onehot = lambda g: (np.arange(C)[:, None] == g[None, :]).astype(T)      # [C, B]
+        gcol, key = onehot(goal[0]), onehot(goal[1])
+        obs = [comm[2], np.concatenate([key, comm[2]], 0), np.concatenate([gcol, key], 0)]
+        sq = lambda c: ((np.square(c[0] - gcol[0]) + np.square(c[1] - gcol[1])) + np.square(c[2] - gcol[2])) \
+            + np.square(c[3] - gcol[3])                                         # np.sum of 4 terms: left to right
+        spoke = lambda c: ~np.all(c == 0, axis=0)
+        with np.errstate(all='ignore'):
+            eve = np.where(spoke(comm[0]), sq(comm[0]), T(0))
+            bob = np.where(spoke(comm[1]), -sq(comm[1]), T(0))
+        rew = np.stack([np.where(spoke(comm[0]), -sq(comm[0]), T(0)), eve + bob, eve + bob]).astype(T)
+        info = np.stack([np.concatenate([comm[i], gcol], 0) for i in range(3)])
+        return obs, rew, info
+
     def _observe_hier(self, pos, vel, lforce):
         """L1F*/S1L* gathers, vectorised (e.g. L1F2_3Targets_100observe.py:136-253)."""
         s, T = self.spec, self.dt
@@ -970,6 +1034,10 @@ class BatchedOracle:
         if s.kind in COMM_KINDS:
             obs, rew, info = self._observe_comm(pos, vel, goal, comm)
             return obs, rew, (info if want_info else None)
+        if s.kind == SIMPLE_CRYPTO:
+            assert s.dim_c == 4
+            obs, rew, info = self._observe_crypto(goal, comm)
+            return obs, rew, (info if want_info else None)
         obs = []
         for i in range(A):
             rows = [vel[i], pos[i]]
@@ -1030,7 +1098,7 @@ class BatchedOracle:
     def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False):
         pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True)
         obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce,
-                                      comm=self.comm_state(act) if self.spec.kind in COMM_KINDS else None)
+                                      comm=self.comm_state(act) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO,) else None)
         if return_lforce:
             return pos, vel, obs, rew, info, lforce
         return pos, vel, obs, rew, info

@@ -289,7 +289,7 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
 
 
 COMM = {k: _load(REF + '/build/lib/multiagent/scenarios/%s.py' % k, 'ref_' + k)
-        for k in ('simple_speaker_listener', 'simple_reference')}      # SURVEY 8f row f1, non-silent half
+        for k in ('simple_speaker_listener', 'simple_reference', 'simple_crypto')}      # SURVEY 8f row f1, non-silent half
 
 
 def rollout_comm(kind, seeds, T):
@@ -297,23 +297,30 @@ def rollout_comm(kind, seeds, T):
     environment.py:198-206; a non-movable agent has no physical entries, :174) and per-agent goal
     landmarks (agent.goal_b).  Actions are stored concatenated agent by agent (act_dims); `comm` is
     agent.state.c after each step; `goal` the landmark index of every agent's goal_b (-1: none)."""
-    keys = ('pos0', 'vel0', 'comm0', 'obs0', 'goal', 'act', 'pos', 'vel', 'comm', 'obs', 'rew')
+    keys = ('pos0', 'vel0', 'comm0', 'obs0', 'goal', 'act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info')
     out = {k: [] for k in keys}
+    crypto = kind == 'simple_crypto'       # goal rows: (goal_a landmark, landmark whose colour is agent 2's key)
     for seed in seeds:
         np.random.seed(seed)
         S = COMM[kind].Scenario()
         world = S.make_world()
         _shim(world)
-        env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation)      # benchmark_data is broken / absent
+        # benchmark_data is broken (speaker_listener) / absent (reference); simple_crypto has one
+        env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data if crypto else None)
         obs0 = env.reset()
         act_dims = [(5 if a.movable else 0) + (0 if a.silent else world.dim_c) for a in world.agents]
         pos0, vel0 = _state(world)
-        out['goal'].append([-1 if a.goal_b is None else world.landmarks.index(a.goal_b) for a in world.agents])
+        if crypto:
+            out['goal'].append([world.landmarks.index(world.agents[0].goal_a), int(np.argmax(world.agents[2].key))])
+        else:
+            out['goal'].append([-1 if a.goal_b is None else world.landmarks.index(a.goal_b) for a in world.agents])
         out['comm0'].append(np.stack([np.asarray(a.state.c, float) for a in world.agents]))
         arng = np.random.RandomState(40_000 + seed)
-        ep = {k: [] for k in ('act', 'pos', 'vel', 'comm', 'obs', 'rew')}
+        ep = {k: [] for k in ('act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info')}
         for t in range(T):
             parts = [arng.rand(n) for n in act_dims]
+            if crypto and t % 5 == 4:          # an all-zero message switches the reward terms off (:104,109,119)
+                parts[(t // 5) % 2] = np.zeros(act_dims[0])
             obs_n, rew_n, done_n, info_n = env.step([p.copy() for p in parts])
             pos, vel = _state(world)
             ep['act'].append(np.concatenate(parts))
@@ -322,12 +329,15 @@ def rollout_comm(kind, seeds, T):
             ep['comm'].append(np.stack([np.asarray(a.state.c, float).copy() for a in world.agents]))
             ep['obs'].append(np.concatenate(obs_n))
             ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
+            ep['info'].append(np.stack([np.concatenate(x) for x in info_n['n']]) if crypto else np.zeros((len(act_dims), 0)))
         out['pos0'].append(pos0)
         out['vel0'].append(vel0)
         out['obs0'].append(np.concatenate(obs0))
         for k in ep:
             out[k].append(np.stack(ep[k]))
     res = {k: np.asarray(v) if k == 'goal' else np.stack(v) for k, v in out.items()}
+    if not crypto:
+        res.pop('info')
     res['seeds'] = np.asarray(list(seeds))
     res['act_dims'] = np.asarray(act_dims)
     res['spec_dim_c'] = np.int64(world.dim_c)
@@ -421,6 +431,7 @@ def main():
                                            actions='softmax'))
     save('g10_simple_speaker_listener', **rollout_comm('simple_speaker_listener', range(48), 25))
     save('g11_simple_reference', **rollout_comm('simple_reference', range(48), 25))
+    save('g12_simple_crypto', **rollout_comm('simple_crypto', range(48), 25))
     # the fork's leader / follower / super-leader pursuit family
     for name, n in (('L1F2_3Targets_100observe', 32), ('S1L2F2_3Targets_100observe', 32),
                     ('L1F2_3Targets_075observe', 8), ('L1F1_10Targets_wide', 16), ('L1F4_3Targets_wide', 16),

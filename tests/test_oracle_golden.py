@@ -305,7 +305,8 @@ def test_target_move_oracle_forms_agree(golden_dir):
     assert total > 10
 
 
-COMM_CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec)]
+COMM_CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec),
+              ('g12_simple_crypto', O.simple_crypto_spec)]
 
 
 @pytest.mark.parametrize('name,mk', COMM_CASES)
@@ -322,15 +323,18 @@ def test_serial_oracle_comm_scenarios_bit_exact(golden_dir, name, mk):
     S, T = g['act'].shape[:2]
     for s in range(S):
         np.random.seed(int(g['seeds'][s]))
-        env = O.SerialEnv(spec, benchmark=False)
+        env = O.SerialEnv(spec, benchmark=spec.kind == O.SIMPLE_CRYPTO)
         env.reset()                                      # make_world() resets once ...
         obs0 = env.reset()                               # ... and env.reset() again
         want_goal = [int(x) for x in g['goal'][s]]
-        got_goal = env.goals if spec.kind == O.SIMPLE_REFERENCE else [env.goals[0], -1]
+        got_goal = {O.SIMPLE_REFERENCE: env.goals, O.SPEAKER_LISTENER: [env.goals[0], -1],
+                    O.SIMPLE_CRYPTO: env.goals[:2]}[spec.kind]
         assert got_goal == want_goal
         assert np.array_equal(np.concatenate(obs0), g['obs0'][s])
         for t in range(T):
-            obs_n, rew_n, _, _ = env.step([g['act'][s, t, offs[i]:offs[i + 1]] for i in range(spec.n_agents)])
+            obs_n, rew_n, _, info_n = env.step([g['act'][s, t, offs[i]:offs[i + 1]] for i in range(spec.n_agents)])
+            if spec.kind == O.SIMPLE_CRYPTO:
+                assert np.array_equal(np.stack(info_n['n']), g['info'][s, t])
             pos, vel = env.get_state()
             assert np.array_equal(pos, g['pos'][s, t]) and np.array_equal(vel, g['vel'][s, t])
             assert np.array_equal(np.stack([a.comm for a in env.agents]), g['comm'][s, t])
@@ -356,3 +360,5 @@ def test_batched_oracle_comm_scenarios_bit_exact(golden_dir, name, mk):
         assert np.array_equal(bo.comm_state(act), np.moveaxis(g['comm'][:, t], 0, -1))
         assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
         assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+        if spec.kind == O.SIMPLE_CRYPTO:
+            assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1))
