@@ -47,6 +47,7 @@ WORKLOADS = {
     # SURVEY 8f row f1, the speaking stock scenarios
     'simple_speaker_listener_2M_f32': ('simple_speaker_listener', {}, 1 << 21, torch.float32),
     'simple_reference_1M_f32': ('simple_reference', {}, 1 << 20, torch.float32),
+    'simple_crypto_2M_f32': ('simple_crypto', {}, 1 << 21, torch.float32),
 }
 
 
@@ -61,7 +62,8 @@ def algorithmic_elems(env, with_info=True):
     # agent.state.c of every agent is rewritten each step once any agent speaks (core.py:224-230)
     extra = (2 * A if w.lforce is not None else 0) + (A * w.dim_c if any(not a.silent for a in w.agents) else 0)
     moving = sum(1 for a in w.agents if a.movable)           # only movable agents have / update a velocity
-    return sum(w.act_dims) + 2 * E + 2 * moving + 4 * moving + obs + A + A * info_w + extra
+    pos_rd = 2 * E if moving else 0                          # simple_crypto: nobody moves, nothing looks at positions
+    return sum(w.act_dims) + pos_rd + 2 * moving + 4 * moving + obs + A + A * info_w + extra
 
 
 def measured_traffic(workload):

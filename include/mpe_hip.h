@@ -67,6 +67,8 @@ extern "C" {
                                   speaking, agent 1 moving and silent; per-env goal landmark (agent 0's goal_b) */
 #define MPE_SIMPLE_REFERENCE 7 /* build/lib/multiagent/scenarios/simple_reference.py: two moving, speaking agents,
                                   one goal landmark per agent (goal_b)                                          */
+#define MPE_SIMPLE_CRYPTO 8    /* build/lib/multiagent/scenarios/simple_crypto.py: adversary, listener, speaker; nobody
+                                  moves, everybody speaks; goal rows = (goal landmark, landmark of the speaker's key) */
 
 /* error codes */
 #define MPE_OK 0
@@ -128,9 +130,10 @@ typedef struct mpe_scenario_desc {
  *                            comm entries when it is not silent (:61-63,198-206)
  *   goal   [goal_rows][ld]   landmark indices: agent.goal_a of simple_adversary / simple_push (1 row),
  *                            agent 0's goal_b of simple_speaker_listener (1 row), every agent's goal_b of
- *                            simple_reference (n_agents rows); see mpe_goal_rows
+ *                            simple_reference (n_agents rows), (goal, key) of simple_crypto (2 rows); see
+ *                            mpe_goal_rows
  *   comm   [A][dim_c][ld]    agent.state.c: written by every world step when not NULL; READ by
- *                            mpe_observe of the two speaking stock scenarios (required there)
+ *                            mpe_observe of the speaking stock scenarios (kinds 6-8; required there)
  *   lforce [A][2][ld]        agent.leader_force (core.py:156-192): written by every world step,
  *                            read by the HIER_PURSUIT observation; NOT touched by reset (like the
  *                            reference's reset_world).  Required when any forced_id >= 0.

@@ -22,7 +22,8 @@ MPE_SIMPLE_PUSH = 4
 MPE_HIER_PURSUIT = 5
 MPE_SPEAKER_LISTENER = 6
 MPE_SIMPLE_REFERENCE = 7
-GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE)
+MPE_SIMPLE_CRYPTO = 8
+GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
 ABI_VERSION = 3
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)

@@ -1,7 +1,8 @@
-// Register-resident env-step kernel for the two speaking stock scenarios in their stock shapes:
+// Register-resident env-step kernels for the speaking stock scenarios in their stock shapes:
 //   MPE_SPEAKER_LISTENER  agent 0 fixed + speaking (3 comm rows), agent 1 moving + silent (5 rows), dim_c 3
 //   MPE_SIMPLE_REFERENCE  two moving + speaking agents (5 + 10 rows each), dim_c 10
-// both with 3 landmarks and no collisions (simple_speaker_listener.py:10-34, simple_reference.py:6-25).
+// both with 3 landmarks and no collisions (simple_speaker_listener.py:10-34, simple_reference.py:6-25),
+// and simple_crypto (crypto_kernel at the end of this file).
 // One env per lane, everything in VGPRs, straight-line (see mpe_small_kernel.h for the access
 // conventions: Win row windows, nontemporal streams, occupancy cap).  Stock flags checked on the host
 // (mpe_hip.hip:comm_variant): nothing collides, no max_speed, no u_noise.  Other shapes run the tile
@@ -164,6 +165,115 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, comm
       }
     }
   }
+}
+
+// simple_crypto in its stock shape (3 fixed speaking agents, 2 landmarks, dim_c 4; simple_crypto.py:24-58):
+// no physics at all -- the step copies the three messages into state.c and scores them against the goal
+// colour.  Pure streaming: 12 action rows in, 12 comm + 20 obs + 3 reward (+ 24 info) rows out.
+template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(THREADS) void crypto_kernel(const KParams<T> p) {
+  constexpr int A = 3, C = 4;
+  const DevDesc<T> &d = p.d;
+  const int64_t ld = p.ld;
+  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;
+  const bool active = blk0 + threadIdx.x < p.B;
+  const uint32_t lo = active ? threadIdx.x : kNoLane;
+  T c[A][C];
+  if (DO_STEP) {
+    const Win<T> wact(p.act + blk0, ld);  // action rows: [c0..c3] per agent (nobody moves)
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int k = 0; k < C; ++k) c[a][k] = wact.ld_stream(a * C + k, lo);
+    if (p.comm != nullptr) {  // core.py:226-230
+      const Win<T> wcomm(p.comm + blk0, ld);
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int k = 0; k < C; ++k) wcomm.st_state(a * C + k, lo, c[a][k]);
+    }
+  } else {
+    const Win<T> wcomm(p.comm + blk0, ld);
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int k = 0; k < C; ++k) c[a][k] = wcomm.ld_state(a * C + k, lo);
+  }
+  if (DO_OBS) {
+    const bool want_rew = p.rew != nullptr, want_stats = p.stats != nullptr;
+    const int64_t gi = blk0 + (active ? threadIdx.x : 0);
+    const int gl = p.goal[gi], key = p.goal[ld + gi];
+    if (p.obs != nullptr) {
+      const Win<T> wobs(p.obs + blk0, ld);  // rows: Eve [c2] | Bob [key, c2] | Alice [goal, key]
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const T kk = k == key ? T(1) : T(0);
+        wobs.st_stream(k, lo, c[2][k]);
+        wobs.st_stream(C + k, lo, kk);
+        wobs.st_stream(2 * C + k, lo, c[2][k]);
+        wobs.st_stream(3 * C + k, lo, k == gl ? T(1) : T(0));
+        wobs.st_stream(4 * C + k, lo, kk);
+      }
+    }
+    if (p.info != nullptr) {  // (agent.state.c, agent.goal_a.color), simple_crypto.py:78-80
+      const Win<T> winfo(p.info + blk0, ld);
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          winfo.st_stream(2 * C * a + k, lo, c[a][k]);
+          winfo.st_stream(2 * C * a + C + k, lo, k == gl ? T(1) : T(0));
+        }
+    }
+    if (want_rew || want_stats) {
+      // simple_crypto.py:96-121: squared error against the goal colour, summed left to right; an all-zero
+      // message switches its term off
+      T err[2];
+      bool spoke[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        T s = T(0);
+        spoke[a] = false;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const T dlt = c[a][k] - (k == gl ? T(1) : T(0));
+          s = k == 0 ? dlt * dlt : s + dlt * dlt;
+          spoke[a] = spoke[a] || c[a][k] != T(0);
+        }
+        err[a] = s;
+      }
+      T rew[A];
+      rew[0] = spoke[0] ? -err[0] : T(0);
+      rew[1] = (spoke[0] ? err[0] : T(0)) + (spoke[1] ? -err[1] : T(0));  // adv_rew + good_rew
+      rew[2] = rew[1];
+      if (want_rew) {
+        const Win<T> wrew(p.rew + blk0, ld);
+#pragma unroll
+        for (int i = 0; i < A; ++i) wrew.st_stream(i, lo, rew[i]);
+      }
+      if (want_stats) {
+        constexpr int W = 2 * A + 2;
+        constexpr int NW = THREADS / 64;
+        __shared__ double sred[NW][A + 1];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+          const double s_r = group_sum(active ? (double)rew[i] : 0.0, 64);
+          if (lane == 0) sred[wave][i] = s_r;
+        }
+        const double n_active = (double)__builtin_popcountll(__ballot(active));  // all lanes vote
+        if (lane == 0) sred[wave][A] = n_active;
+        __syncthreads();
+        if (threadIdx.x <= A) {
+          double s = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += sred[w][threadIdx.x];
+          p.stats[(int64_t)blockIdx.x * W + (threadIdx.x < A ? threadIdx.x : 2 * A + 1)] += s;
+        }
+      }
+    }
+  }
+  (void)d;
 }
 
 }  // namespace mpe

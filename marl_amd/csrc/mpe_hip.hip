@@ -32,6 +32,7 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
     const int nt = L < h->n_target_obs ? L : h->n_target_obs;
     return 4 + 4 * (A - 1) + (h->forced_id[i] >= 0 ? 2 : 0) + 2 * nt;
   }
+  if (h->kind == MPE_SIMPLE_CRYPTO) return h->adversary[i] ? h->dim_c : 2 * h->dim_c;  // simple_crypto.py:153-171
   if (h->kind == MPE_SPEAKER_LISTENER)  // simple_speaker_listener.py:89-94
     return h->movable[i] ? 2 + 2 * L + h->dim_c * (A - 1) : 3;
   if (h->kind == MPE_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + h->dim_c * (A - 1);  // simple_reference.py:89
@@ -48,13 +49,16 @@ static bool kind_has_roles(int kind) {
          kind == MPE_HIER_PURSUIT;
 }
 static bool kind_is_comm(int kind) { return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE; }
-static bool kind_is_ragged(int kind) { return kind == MPE_HIER_PURSUIT || kind_is_comm(kind); }
+// kinds whose observations contain another agent's state.c (read from the comm buffer when only observing)
+static bool kind_reads_comm(int kind) { return kind_is_comm(kind) || kind == MPE_SIMPLE_CRYPTO; }
+static bool kind_is_ragged(int kind) { return kind == MPE_HIER_PURSUIT || kind_reads_comm(kind); }
 // environment.py:42-76: 5 physical entries for a movable agent, dim_c comm entries for a speaking one
 static int act_dim_of(const mpe_scenario_desc *h, int i) {
   return (h->movable[i] ? 5 : 0) + (h->silent[i] ? 0 : h->dim_c);
 }
 static int goal_rows_of(const mpe_scenario_desc *h) {
   if (h->kind == MPE_SIMPLE_ADVERSARY || h->kind == MPE_SIMPLE_PUSH || h->kind == MPE_SPEAKER_LISTENER) return 1;
+  if (h->kind == MPE_SIMPLE_CRYPTO) return 2;  // goal landmark, landmark of the speaker's key
   return h->kind == MPE_SIMPLE_REFERENCE ? h->n_agents : 0;
 }
 static bool has_lforce(const mpe_scenario_desc *h) {
@@ -69,6 +73,7 @@ static int info_width_of(const mpe_scenario_desc *h) {
     case MPE_HIER_PURSUIT: return 1;  // L1F2_3Targets_100observe.py:136-148
     case MPE_SIMPLE_SPREAD: return 4;
     case MPE_SIMPLE_ADVERSARY: return h->n_landmarks + 1;  // simple_adversary.py:58-67
+    case MPE_SIMPLE_CRYPTO: return 2 * h->dim_c;           // (state.c, goal colour), simple_crypto.py:78-80
     default: return 0;                                     // simple.py / simple_push.py: no benchmark_data
   }
 }
@@ -93,7 +98,7 @@ extern "C" const char *mpe_strerror(int code) {
 
 extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   if (!h) return MPE_ERR_NULL;
-  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_SIMPLE_REFERENCE) return MPE_ERR_UNSUPPORTED;
+  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_SIMPLE_CRYPTO) return MPE_ERR_UNSUPPORTED;
   if (h->n_agents < 1 || h->n_agents > MPE_MAX_AGENTS) return MPE_ERR_DESC;
   if (h->n_landmarks < 0 || h->n_agents + h->n_landmarks > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
   if (h->dim_c < 0 || h->dim_c > 16) return MPE_ERR_DESC;
@@ -132,6 +137,14 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
     if (h->kind == MPE_SPEAKER_LISTENER &&
         (h->movable[0] || h->silent[0] || !h->movable[1] || !h->silent[1]))  // speaker, then listener
       return MPE_ERR_DESC;
+  }
+  if (h->kind == MPE_SIMPLE_CRYPTO) {
+    // Eve, Bob, Alice by index (simple_crypto.py:33-35,62-63); colours are one-hots over dim_c (:55-59);
+    // dim_c <= 7 keeps np.sum's left-to-right order (pairwise summation starts at 8 elements)
+    if (h->n_agents != 3 || h->n_landmarks != 2 || h->dim_c < 2 || h->dim_c > 7) return MPE_ERR_DESC;
+    if (!h->adversary[0] || h->adversary[1] || h->adversary[2]) return MPE_ERR_DESC;
+    for (int a = 0; a < 3; ++a)
+      if (h->movable[a] || h->silent[a]) return MPE_ERR_DESC;
   }
   if (h->kind == MPE_SIMPLE && h->n_landmarks < 1) return MPE_ERR_DESC;
   if (kind_has_goal(h->kind)) {  // a goal landmark and at least one good agent must exist
@@ -230,7 +243,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     d.accel[a] = (T)h->accel[a];
     d.max_speed[a] = (T)h->max_speed[a];
     d.u_noise[a] = (T)h->u_noise[a];
-    if (kind_has_roles(h->kind) && h->adversary[a]) {
+    if ((kind_has_roles(h->kind) || h->kind == MPE_SIMPLE_CRYPTO) && h->adversary[a]) {
       d.adversary[a >> 5] |= 1u << (a & 31);
       d.adv_list[d.n_adv++] = (uint8_t)a;
     } else {
@@ -273,7 +286,8 @@ enum SmallId {
   HIER_LAST = HIER_5_10_2,
   // speaking stock scenarios (mpe_comm_kernel.h)
   COMM_SPEAKER_LISTENER,
-  COMM_REFERENCE
+  COMM_REFERENCE,
+  COMM_CRYPTO
 };
 
 // Stock shape of simple_speaker_listener / simple_reference (mpe_comm_kernel.h header), or SMALL_NONE.
@@ -326,6 +340,7 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
     case MPE_HIER_PURSUIT: return hier_variant(h);
     case MPE_SPEAKER_LISTENER:
     case MPE_SIMPLE_REFERENCE: return comm_variant(h);
+    case MPE_SIMPLE_CRYPTO: return h->dim_c == 4 ? COMM_CRYPTO : SMALL_NONE;  // roles, shape: mpe_desc_check
     default: return SMALL_NONE;
   }
   for (int a = 0; a < A; ++a) {
@@ -407,6 +422,11 @@ static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStrea
       case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
       case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
       case COMM_REFERENCE: return launch_comm<T, MPE_SIMPLE_REFERENCE, 10, DO_STEP, DO_OBS>(p, s);
+      case COMM_CRYPTO: {
+        const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+        hipLaunchKernelGGL((crypto_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
       default: break;
     }
   }
@@ -472,7 +492,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   const bool lf = has_lforce(h);
   if (lf && !b->lforce) return MPE_ERR_NULL;
   if (do_obs && goal_rows_of(h) > 0 && !b->goal) return MPE_ERR_NULL;
-  if (do_obs && !do_step && kind_is_comm(h->kind) && !b->comm) return MPE_ERR_NULL;  // observed agent.state.c
+  if (do_obs && !do_step && kind_reads_comm(h->kind) && !b->comm) return MPE_ERR_NULL;  // observed agent.state.c
   p.pos = (T *)b->pos;
   p.vel = (T *)b->vel;
   p.lforce = lf ? (T *)b->lforce : nullptr;

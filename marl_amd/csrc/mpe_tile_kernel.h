@@ -187,6 +187,25 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+          if (HIER && d.kind == MPE_SIMPLE_CRYPTO) {
+            // simple_crypto.py:124-171: speaker [goal colour, key]; listener [key, speaker's c]; adversary [speaker's c]
+            const int C = d.dim_c;
+            const int gl = p.goal[ge], key = p.goal[ld + ge];
+            if (i == 2) {
+              for (int k = 0; k < C; ++k) { st_stream(o, k == gl ? T(1) : T(0)); o += ld; }
+            }
+            if (i != 0) {
+              for (int k = 0; k < C; ++k) { st_stream(o, k == key ? T(1) : T(0)); o += ld; }
+            }
+            if (i != 2) {
+              for (int k = 0; k < C; ++k) {
+                st_stream(o, DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[2] + k) * ld + env)
+                                     : p.comm[(int64_t)(2 * C + k) * ld + env]);
+                o += ld;
+              }
+            }
+            continue;
+          }
           if (HIER && kind_is_comm(d.kind)) {
             // simple_speaker_listener.py:72-94 / simple_reference.py:62-89
             const bool ref = d.kind == MPE_SIMPLE_REFERENCE;
@@ -395,6 +414,47 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_t = group_sum(active ? (double)total : 0.0, TILE);
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        } else if (HIER && d.kind == MPE_SIMPLE_CRYPTO) {
+          // simple_crypto.py:78-121: squared error of Eve's / Bob's message against the goal colour; an
+          // all-zero message switches its term off.  Every chunk recomputes the two sums (tiny world).
+          const int C = d.dim_c;
+          const int gl = p.goal[ge];
+          auto msg = [&](int a, int k) {
+            return DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[a] + k) * ld + ge)
+                           : p.comm[(int64_t)(a * C + k) * ld + ge];
+          };
+          T err[2];
+          bool spoke[2];
+          for (int a = 0; a < 2; ++a) {
+            T s = T(0);
+            bool any = false;
+            for (int k = 0; k < C; ++k) {
+              const T c = msg(a, k), dlt = c - (k == gl ? T(1) : T(0));
+              s = k == 0 ? dlt * dlt : s + dlt * dlt;  // np.sum: left to right
+              any = any || c != T(0);
+            }
+            err[a] = s;
+            spoke[a] = any;
+          }
+          const T eve = spoke[0] ? err[0] : T(0);
+          const T r_good = eve + (spoke[1] ? -err[1] : T(0));  // adv_rew + good_rew (:114)
+          for (int i = chunk; i < A; i += NCH) {
+            const T r_i = i == 0 ? (spoke[0] ? -err[0] : T(0)) : r_good;
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_info && active) {  // (agent.state.c, agent.goal_a.color)
+              T *ir = p.info + (int64_t)(2 * C * i) * ld + env;
+              for (int k = 0; k < C; ++k) st_stream(ir + (int64_t)k * ld, msg(i, k));
+              for (int k = 0; k < C; ++k) st_stream(ir + (int64_t)(C + k) * ld, k == gl ? T(1) : T(0));
+            }
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              if (lane == 0) srow[i] += s_r;
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) srow[2 * A + 1] += s_n;
           }
         } else if (HIER && kind_is_comm(d.kind)) {
           // simple_speaker_listener.py:66-70 (both agents: listener to agent 0's goal) /

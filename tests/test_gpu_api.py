@@ -365,3 +365,43 @@ def test_speaking_scenarios_episode_loop_matches_oracle(name, mk):
         env.reset()
         with pytest.raises(NameError):
             env.step([torch.rand(4, d, device='cuda', dtype=torch.float64) for d in spec.act_dims])
+
+
+def test_simple_crypto_episode_loop_matches_oracle():
+    """simple_crypto through the public API with benchmark=True: Discrete(4) spaces for three agents that
+    only speak, info = (state.c, goal colour) (simple_crypto.py:78-80), rewards with the all-zero-message
+    switch (:104,109,119)."""
+    from marl_amd import make_env, spaces
+    spec = O.simple_crypto_spec()
+    B, T = 320, 25
+    env = make_env('simple_crypto', benchmark=True, num_envs=B, dtype=torch.float64, seed=4)
+    assert env.action_space == [spaces.Discrete(4)] * 3
+    assert [s.shape[0] for s in env.observation_space] == [4, 8, 8]
+    obs_n = env.reset()
+    w = env.world
+    ids = np.arange(B, dtype=np.uint64)
+    goal = w.goal.cpu().numpy().reshape(2, B)
+    assert np.array_equal(goal, O.reset_goals(spec, 4, w.episode - 1, ids).reshape(2, B))
+    assert set(np.unique(goal)) == {0, 1}
+    bo = O.BatchedOracle(spec)
+    pos, vel = _np(w.pos), _np(w.vel)
+    obs0, _, _ = bo.observe(pos, vel, goal=goal)
+    for i in range(3):
+        assert np.array_equal(_np(obs_n[i]).T, obs0[i])
+    gen = torch.Generator(device='cuda').manual_seed(6)
+    onehot = np.eye(4)[goal[0]]                                           # [B, 4] goal colour
+    for t in range(T):
+        action_n = [torch.rand(B, 4, generator=gen, device='cuda', dtype=torch.float64) for _ in range(3)]
+        action_n[t % 3][::5] = 0.0                                        # some agents stay silent
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        act = np.concatenate([_np(a).T for a in action_n], 0)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, goal=goal)
+        assert np.array_equal(_np(w.pos), pos)                            # nobody moves
+        for i, a in enumerate(w.agents):
+            assert np.array_equal(_np(new_obs_n[i]).T, obs[i])
+            assert np.array_equal(_np(a.state.c), _np(action_n[i]))
+            c, colour = info_n['n'][i]
+            assert np.array_equal(_np(c), _np(action_n[i])) and np.array_equal(_np(colour), onehot)
+        np.testing.assert_allclose(np.stack([_np(x) for x in rew_n]), rew, rtol=0, atol=1e-9)
+        silent = ~_np(action_n[0]).any(1)
+        assert (np.stack([_np(x) for x in rew_n])[0][silent] == 0).all()

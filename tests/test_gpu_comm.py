@@ -1,5 +1,6 @@
-"""GPU parity for the speaking stock scenarios of SURVEY 8f row f1: simple_speaker_listener and
-simple_reference (ragged actions, agent.state.c observed by the other agent, per-agent goal_b)
+"""GPU parity for the speaking stock scenarios of SURVEY 8f row f1: simple_speaker_listener,
+simple_reference (ragged actions, agent.state.c observed by the other agent, per-agent goal_b) and
+simple_crypto (nobody moves, messages scored against the goal colour, benchmark info)
 through the C ABI, against the golden vectors generated from the reference and the CPU oracle.
 f64 <= 1e-9 over free-running 25-step episodes; f32 <= 1e-4 (no thresholds in these scenarios)."""
 import os
@@ -15,7 +16,25 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from tests.gpu_util import HipSim, dev, golden_soa, lib
 
-CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec)]
+CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec),
+         ('g12_simple_crypto', O.simple_crypto_spec)]
+SPECS = pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec, O.simple_crypto_spec],
+                                ids=['speaker_listener', 'reference', 'crypto'])
+
+
+def _messages(rng, spec, B):
+    """Random action rows; every 7th env sends an all-zero message from agent (env // 7) % A (the
+    switch simple_crypto's rewards have, simple_crypto.py:104,109,119)."""
+    an = rng.rand(sum(spec.act_dims), B)
+    envs = np.arange(0, B, 7)
+    offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    for a in range(spec.n_agents):
+        if spec.silent[a]:
+            continue
+        sel = envs[(envs // 7) % spec.n_agents == a]
+        r0 = offs[a] + spec.comm_row0(a)
+        an[r0:r0 + spec.dim_c, sel] = 0.0
+    return an
 
 
 def _load(golden_dir, name):
@@ -35,15 +54,15 @@ def force_tile(request):
     lib.mpe_debug_force_tile_kernel(0)
 
 
-@pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
+@SPECS
 def test_register_and_tile_kernels_bit_identical(mk):
     spec = mk()
     B = 4096 + 11
     rng = np.random.RandomState(8)
     pos = rng.uniform(-1, 1, (spec.n_entities, 2, B))
     vel = rng.uniform(-0.5, 0.5, (spec.n_agents, 2, B))
-    goal = rng.randint(0, 3, (spec.goal_rows, B))
-    acts = rng.rand(4, sum(spec.act_dims), B)
+    goal = rng.randint(0, spec.n_landmarks, (spec.goal_rows, B))
+    acts = np.stack([_messages(rng, spec, B) for _ in range(4)])
     for dtype in (torch.float64, torch.float32):
         res = []
         for ft in (0, 1):
@@ -81,14 +100,15 @@ def test_trajectory_matches_reference(golden_dir, name, mk, dtype, tol, force_ti
         pos, vel, obs, rew, info = sim.host()
         errs = (_maxerr(pos, golden_soa(g, 'pos', t)), _maxerr(vel, golden_soa(g, 'vel', t)),
                 _maxerr(sim.comm[..., :S].double().cpu().numpy(), golden_soa(g, 'comm', t)),
-                _maxerr(obs, g['obs'][:, t].T))
+                _maxerr(obs, g['obs'][:, t].T),
+                _maxerr(info, golden_soa(g, 'info', t)) if 'info' in g.files else 0.0)
         rerr = np.abs(rew - golden_soa(g, 'rew', t)) / np.maximum(1.0, np.abs(golden_soa(g, 'rew', t)))
         worst = max(worst, *errs, float(rerr.max()))
         assert max(errs) <= tol and rerr.max() <= tol, (name, t, errs, rerr.max())
     print('%s %s worst |err| = %.3e' % (name, dtype, worst))
 
 
-@pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
+@SPECS
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
 def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtype, force_tile):
     """mpe_world_step + mpe_observe (which reads agent.state.c from the comm buffer) == mpe_env_step
@@ -99,7 +119,7 @@ def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtyp
     rng = np.random.RandomState(5)
     pos = rng.uniform(-1, 1, (spec.n_entities, 2, B))
     vel = rng.uniform(-0.5, 0.5, (spec.n_agents, 2, B))
-    goal = rng.randint(0, 3, (spec.goal_rows, B))
+    goal = rng.randint(0, spec.n_landmarks, (spec.goal_rows, B))
     a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
     a.set_state(pos, vel, goal)
     b.set_state(pos, vel, goal)
@@ -108,7 +128,7 @@ def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtyp
     bo = O.BatchedOracle(spec)
     want_sum = np.zeros(spec.n_agents)
     for t in range(steps):
-        an = rng.rand(sum(spec.act_dims), B)
+        an = _messages(rng, spec, B)
         act = torch.zeros(sum(spec.act_dims), ld, dtype=dtype, device='cuda')
         act[:, :B] = dev(an, dtype)
         a.env_step(act, comm=a.comm, stats=stats)
@@ -121,6 +141,8 @@ def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtyp
             pos, vel, obs, rew, info = bo.env_step(pos, vel, an, goal=goal)
             gp, gv, go, gr, gi = a.host()
             assert max(_maxerr(gp, pos), _maxerr(gv, vel), _maxerr(go, np.concatenate(obs, 0)), _maxerr(gr, rew)) <= 1e-9
+            if spec.info_width:
+                assert _maxerr(gi, info) == 0.0
             assert _maxerr(a.comm[..., :B].cpu().numpy(), bo.comm_state(an)) == 0.0
             want_sum += rew.sum(1)
     for t_ in (a.obs, a.rew):
@@ -133,7 +155,7 @@ def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtyp
         assert out[2 * spec.n_agents + 1].item() == steps * B
 
 
-@pytest.mark.parametrize('mk', [O.speaker_listener_spec, O.simple_reference_spec], ids=['speaker_listener', 'reference'])
+@SPECS
 def test_reset_draws_goals_from_the_philox_oracle(mk):
     spec = mk()
     B = 2048
@@ -144,4 +166,4 @@ def test_reset_draws_goals_from_the_philox_oracle(mk):
                           O.reset_goals(spec, 11, 4, ids).reshape(spec.goal_rows, B))
     assert np.array_equal(sim.pos.cpu().numpy(), O.reset_positions(spec, 11, 4, ids))
     g = sim.goal[:spec.goal_rows].cpu().numpy()
-    assert g.min() == 0 and g.max() == 2 and (spec.goal_rows == 1 or (g[0] != g[1]).mean() > 0.5)
+    assert g.min() == 0 and g.max() == spec.n_landmarks - 1 and (spec.goal_rows == 1 or (g[0] != g[1]).mean() > 0.4)

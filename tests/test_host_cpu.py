@@ -234,3 +234,35 @@ def test_comm_scenarios_geometry_and_validation():
         w = sc.make_world()
         spec = O.speaker_listener_spec() if kind == _hip.MPE_SPEAKER_LISTENER else O.simple_reference_spec()
         assert bytes(w.descriptor()) == bytes(_desc(spec))
+
+
+def test_simple_crypto_geometry_and_validation():
+    """simple_crypto: nobody moves (dim_c action rows each), two goal rows (goal, key), info = (c, goal colour),
+    roles pinned by the descriptor check."""
+    from marl_amd import _hip
+    import marl_amd.scenarios as scenarios
+    lib = _hip.lib
+    spec = O.simple_crypto_spec()
+    d = _desc(spec)
+    assert lib.mpe_desc_check(d) == 0
+    assert [lib.mpe_act_dim(d, i) for i in range(3)] == spec.act_dims == [4, 4, 4]
+    assert [lib.mpe_obs_dim(d, i) for i in range(3)] == spec.obs_dims == [4, 8, 8]
+    assert lib.mpe_goal_rows(d) == 2 and lib.mpe_info_width(d) == spec.info_width == 8
+    for field, idx, val in (('movable', 1, 1), ('silent', 0, 1), ('adversary', 1, 1), ('adversary', 0, 0)):
+        bad = _hip.ScenarioDesc.from_buffer_copy(d)
+        getattr(bad, field)[idx] = val
+        assert lib.mpe_desc_check(bad) in (-2, -5), field
+    for field, val in (('n_landmarks', 3), ('dim_c', 8), ('dim_c', 1)):
+        bad = _hip.ScenarioDesc.from_buffer_copy(d)
+        setattr(bad, field, val)
+        assert lib.mpe_desc_check(bad) == -2, field
+    b = _hip.Buffers()
+    b.pos, b.vel, b.obs, b.goal = 8, 8, 8, 8
+    assert lib.mpe_observe_f64(d, 4, 4, b, None) == -1        # observing needs agent.state.c (comm)
+    sc = scenarios.load('simple_crypto.py').Scenario()
+    sc._finish_world = lambda world: world
+    w = sc.make_world()
+    assert bytes(w.descriptor()) == bytes(d)
+    assert [a.speaker for a in w.agents] == [False, False, True]
+    assert sc.good_listeners(w) == [w.agents[1]] and sc.adversaries(w) == [w.agents[0]]
+
