@@ -41,6 +41,7 @@ HIER_PURSUIT = 5       # multiagent/scenarios/{L1F*,S1L*}.py: the fork's leader/
 SPEAKER_LISTENER = 6   # build/lib/multiagent/scenarios/simple_speaker_listener.py  (comm half)
 SIMPLE_REFERENCE = 7   # build/lib/multiagent/scenarios/simple_reference.py
 SIMPLE_CRYPTO = 8      # build/lib/multiagent/scenarios/simple_crypto.py (nobody moves: messages only)
+WORLD_COMM = 9         # build/lib/multiagent/scenarios/simple_world_comm.py (tag physics, food, forests, a speaking leader)
 COMM_KINDS = (SPEAKER_LISTENER, SIMPLE_REFERENCE)   # per-agent goal landmark (agent.goal_b) + observed comm
 # landmark.color tables (simple_speaker_listener.py:48-50 / simple_reference.py:41-43): (base, highlighted)
 COMM_COLORS = {SPEAKER_LISTENER: (0.15, 0.65), SIMPLE_REFERENCE: (0.25, 0.75)}
@@ -80,6 +81,10 @@ class ScenarioSpec:
     reward_variant: int = 0                          # 1 = S1L2F2_10Targets_wide_rewardFixed.py
     advfollower: Optional[Sequence[bool]] = None     # agents whose touch respawns a target (train_and_eval.py:216)
     n_target_obs: int = 3                            # target_pos[0:3]
+    # simple_world_comm.py:19-57: world.landmarks = plain landmarks + food + forests, in that order
+    n_food: int = 0
+    n_forests: int = 0
+    leader: Optional[Sequence[bool]] = None          # agent.leader (simple_world_comm.py:27): sees through forests
 
     def __post_init__(self):
         A = self.n_agents
@@ -95,6 +100,8 @@ class ScenarioSpec:
             self.advsuperleader = [False] * A
         if self.obs_r is None:
             self.obs_r = [0.0] * A
+        if self.leader is None:
+            self.leader = [False] * A
         if self.advfollower is None:                 # L1F2_3Targets_100observe.py:40,52,64: the silent adversaries
             self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind == HIER_PURSUIT
                                 for i in range(A)]
@@ -142,6 +149,9 @@ class ScenarioSpec:
             return 2 + 2 * L + 3 + self.dim_c * (A - 1)
         if self.kind == SIMPLE_CRYPTO:          # simple_crypto.py:153-171: adversary / listener / speaker
             return self.dim_c if self.adversary[i] else 2 * self.dim_c
+        if self.kind == WORLD_COMM:             # simple_world_comm.py:305-313
+            n_good_others = sum(1 for j in range(A) if j != i and not self.adversary[j])
+            return 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others + 2 + (self.dim_c if self.adversary[i] else 0)
         if self.kind == SIMPLE:                 # simple.py:50
             return 2 + 2 * L
         if self.kind == SIMPLE_ADVERSARY:       # simple_adversary.py:137-140
@@ -162,7 +172,7 @@ class ScenarioSpec:
             return 2 * self.dim_c
         if self.kind in (SIMPLE, SIMPLE_PUSH) + COMM_KINDS:  # no (working) benchmark_data in these scenarios
             return 0
-        return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT) else 4
+        return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT, WORLD_COMM) else 4
 
 
 def simple_tag_spec(n_adv=3, n_good=1, n_landmarks=2, u_noise=None):
@@ -235,6 +245,21 @@ def simple_crypto_spec():
         size=[0.05] * 5, accel=[None] * 3, max_speed=[None] * 3, collide=[False] * 5, movable=[False] * 5,
         u_noise=[None] * 3, mass=[1.0] * 5, agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=4,
         silent=[False] * 3)
+
+
+def simple_world_comm_spec(n_adv=4, n_good=2, n_plain=1, n_food=2, n_forests=2):
+    """simple_world_comm.py:11-61: simple_tag roles and physics; agent 0 is the leader and the only speaker;
+    landmarks = 1 colliding obstacle + 2 food + 2 forests (food and forests do not collide)."""
+    A, L = n_adv + n_good, n_plain + n_food + n_forests
+    adv = [i < n_adv for i in range(A)]
+    return ScenarioSpec(
+        kind=WORLD_COMM, n_agents=A, n_landmarks=L, adversary=adv,
+        size=[0.075 if a else 0.045 for a in adv] + [0.2] * n_plain + [0.03] * n_food + [0.3] * n_forests,
+        accel=[3.0 if a else 4.0 for a in adv], max_speed=[1.0 if a else 1.3 for a in adv],
+        collide=[True] * A + [True] * n_plain + [False] * (n_food + n_forests),
+        movable=[True] * A + [False] * L, u_noise=[None] * A, mass=[1.0] * (A + L),
+        agent_pos_range=1.0, landmark_pos_range=0.9, dim_c=4, silent=[i > 0 for i in range(A)],
+        n_food=n_food, n_forests=n_forests, leader=[i == 0 for i in range(A)])
 
 
 def simple_spec():
@@ -339,6 +364,9 @@ class SerialEnv:
         for lm in self.landmarks:
             lm.pos = np.random.uniform(-s.landmark_pos_range, +s.landmark_pos_range, 2)
             lm.vel = np.zeros(2)
+        if s.kind == WORLD_COMM:         # simple_world_comm.py:112-117: food, then forests, are drawn a second time
+            for lm in self.landmarks[s.n_landmarks - s.n_forests - s.n_food:]:
+                lm.pos = np.random.uniform(-s.landmark_pos_range, +s.landmark_pos_range, 2)
         return [self.observation(i) for i in range(self.n)]
 
     # -- environment.py:157-208 (Discrete(5) soft one-hot path) --------------------------
@@ -542,6 +570,31 @@ class SerialEnv:
             if not me.adversary:
                 return np.concatenate([key] + comm)
             return np.concatenate(comm)
+        if kind == WORLD_COMM:                                   # simple_world_comm.py:230-313
+            s = self.spec
+            forests = self.landmarks[s.n_landmarks - s.n_forests:]
+            assert len(forests) == 2
+            entity_pos = [lm.pos - me.pos for lm in self.landmarks]
+            inf = [self._touching(me, f) for f in forests]
+            in_forest = [np.array([1]) if x else np.array([-1]) for x in inf]
+            other_pos, other_vel = [], []
+            for other in self.agents:
+                if other is me:
+                    continue
+                oth = [self._touching(other, f) for f in forests]
+                if (inf[0] and oth[0]) or (inf[1] and oth[1]) or (not inf[0] and not oth[0] and not inf[1] and not oth[1]) \
+                        or s.leader[i]:
+                    other_pos.append(other.pos - me.pos)
+                    if not other.adversary:
+                        other_vel.append(other.vel)
+                else:
+                    other_pos.append([0, 0])
+                    if not other.adversary:
+                        other_vel.append([0, 0])
+            comm = [self.agents[0].comm]
+            if me.adversary:                                     # leader and the other adversaries alike (:305-310)
+                return np.concatenate([me.vel] + [me.pos] + entity_pos + other_pos + other_vel + in_forest + comm)
+            return np.concatenate([me.vel] + [me.pos] + entity_pos + other_pos + in_forest + other_vel)
         if kind in COMM_KINDS:
             base, hi = COMM_COLORS[kind]
             color = np.full(3, base)
@@ -600,6 +653,38 @@ class SerialEnv:
             if not (eve.comm == zero).all():
                 adv_rew += np.sum(np.square(eve.comm - goal_color))
             return adv_rew + good_rew
+        if kind == WORLD_COMM:                                   # simple_world_comm.py:146-204
+            s = self.spec
+            advs = [a for a in self.agents if a.adversary]
+            goods = [a for a in self.agents if not a.adversary]
+            food = self.landmarks[s.n_landmarks - s.n_forests - s.n_food:s.n_landmarks - s.n_forests]
+            rew = 0
+            if me.adversary:
+                rew -= 0.1 * min([np.sqrt(np.sum(np.square(a.pos - me.pos))) for a in goods])
+                if me.collide:
+                    for ag in goods:
+                        for adv in advs:
+                            if self._touching(ag, adv):
+                                rew += 5
+                return rew
+            if me.collide:
+                for a in advs:
+                    if self._touching(a, me):
+                        rew -= 5
+            for p in range(2):
+                x = abs(me.pos[p])
+                if x < 0.9:
+                    pen = 0
+                elif x < 1.0:
+                    pen = (x - 0.9) * 10
+                else:
+                    pen = min(np.exp(2 * x - 2), 10)
+                rew -= 2 * pen
+            for f in food:
+                if self._touching(me, f):
+                    rew += 2
+            rew += 0.05 * min([np.sqrt(np.sum(np.square(f.pos - me.pos))) for f in food])
+            return rew
         if kind == SPEAKER_LISTENER:                             # simple_speaker_listener.py:66-70
             return -self._sq(self.agents[1], self.landmarks[self.goals[0]])
         if kind == SIMPLE_REFERENCE:                             # simple_reference.py:56-60 (goal_a = the other agent)
@@ -668,7 +753,7 @@ class SerialEnv:
             return tuple([self._sq(me, lm) for lm in self.landmarks] + [self._sq(me, goal)])
         if self.spec.kind in (SIMPLE, SIMPLE_PUSH):
             return {}
-        if self.spec.kind == SIMPLE_TAG:           # simple_tag.py:57-66
+        if self.spec.kind in (SIMPLE_TAG, WORLD_COMM):   # simple_tag.py:57-66, simple_world_comm.py:119-127
             if not me.adversary:
                 return 0
             return sum(1 for g in self.agents if not g.adversary and self._touching(g, me))
@@ -1017,6 +1102,73 @@ class BatchedOracle:
                         rew[i] = -np.sqrt(sq(pos[i], gp))
         return obs, rew, info
 
+    def _observe_world_comm(self, pos, vel, comm):
+        """simple_world_comm.py:119-313, vectorised over envs in the reference's operation order."""
+        s, T = self.spec, self.dt
+        A, L = s.n_agents, s.n_landmarks
+        B = pos.shape[-1]
+        assert s.n_forests == 2
+        comm = np.zeros((A, s.dim_c, B), T) if comm is None else np.asarray(comm, T)
+        f0 = A + L - s.n_forests
+        food = list(range(A + L - s.n_forests - s.n_food, A + L - s.n_forests))
+        advs = [i for i in range(A) if s.adversary[i]]
+        goods = [i for i in range(A) if not s.adversary[i]]
+        with np.errstate(all='ignore'):
+            touch = lambda a, b: self._dist(pos, a, b) < T(s.size[a] + s.size[b])
+            inf = [[touch(i, f0 + k) for k in range(2)] for i in range(A)]
+            obs = []
+            for i in range(A):
+                rows = [vel[i], pos[i]] + [pos[A + l] - pos[i] for l in range(L)]
+                other_vel = []
+                for j in range(A):
+                    if j == i:
+                        continue
+                    vis = ((inf[i][0] & inf[j][0]) | (inf[i][1] & inf[j][1])
+                           | (~inf[i][0] & ~inf[j][0] & ~inf[i][1] & ~inf[j][1]))
+                    if s.leader[i]:
+                        vis = np.ones(B, bool)
+                    rows.append(np.where(vis, pos[j] - pos[i], T(0)))
+                    if not s.adversary[j]:
+                        other_vel.append(np.where(vis, vel[j], T(0)))
+                in_forest = [np.where(inf[i][k], T(1), T(-1))[None] for k in range(2)]
+                if s.adversary[i]:
+                    rows += other_vel + in_forest + [comm[0]]
+                else:
+                    rows += in_forest + other_vel
+                obs.append(np.concatenate(rows, axis=0))
+            rew = np.zeros((A, B), T)
+            info = np.zeros((A, 1, B), T)
+            for i in advs:
+                m = self._dist(pos, goods[0], i)
+                for g in goods[1:]:
+                    m = np.minimum(m, self._dist(pos, g, i))
+                r = T(0) - T(0.1) * m
+                if s.collide[i]:
+                    for g in goods:
+                        for a in advs:
+                            r = r + T(5) * touch(g, a)
+                rew[i] = r
+                for g in goods:
+                    info[i, 0] += touch(g, i)
+            for i in goods:
+                r = np.zeros(B, T)
+                if s.collide[i]:
+                    for a in advs:
+                        r = r - T(5) * touch(a, i)
+                for p in range(2):
+                    x = np.abs(pos[i, p])
+                    bnd = np.where(x < T(0.9), T(0),
+                                   np.where(x < T(1.0), (x - T(0.9)) * T(10),
+                                            np.minimum(np.exp(T(2) * x - T(2)), T(10))))
+                    r = r - T(2) * bnd
+                for f in food:
+                    r = r + T(2) * touch(i, f)
+                m = self._dist(pos, food[0], i)
+                for f in food[1:]:
+                    m = np.minimum(m, self._dist(pos, f, i))
+                rew[i] = r + T(0.05) * m
+        return obs, rew, info
+
     def observe(self, pos, vel, want_info=True, goal=None, lforce=None, comm=None):
         """Returns obs (list of [dim_i, B]), rew [A,B], info [A,W,B]."""
         s, T = self.spec, self.dt
@@ -1037,6 +1189,9 @@ class BatchedOracle:
         if s.kind == SIMPLE_CRYPTO:
             assert s.dim_c == 4
             obs, rew, info = self._observe_crypto(goal, comm)
+            return obs, rew, (info if want_info else None)
+        if s.kind == WORLD_COMM:
+            obs, rew, info = self._observe_world_comm(pos, vel, comm)
             return obs, rew, (info if want_info else None)
         obs = []
         for i in range(A):
@@ -1098,7 +1253,7 @@ class BatchedOracle:
     def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False):
         pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True)
         obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce,
-                                      comm=self.comm_state(act) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO,) else None)
+                                      comm=self.comm_state(act) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO, WORLD_COMM) else None)
         if return_lforce:
             return pos, vel, obs, rew, info, lforce
         return pos, vel, obs, rew, info

@@ -289,10 +289,11 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
 
 
 COMM = {k: _load(REF + '/build/lib/multiagent/scenarios/%s.py' % k, 'ref_' + k)
-        for k in ('simple_speaker_listener', 'simple_reference', 'simple_crypto')}      # SURVEY 8f row f1, non-silent half
+        for k in ('simple_speaker_listener', 'simple_reference', 'simple_crypto',
+                  'simple_world_comm')}                                                    # SURVEY 8f row f1, non-silent half
 
 
-def rollout_comm(kind, seeds, T):
+def rollout_comm(kind, seeds, T, init=None):
     """simple_speaker_listener / simple_reference: agents that speak (comm entries in the action,
     environment.py:198-206; a non-movable agent has no physical entries, :174) and per-agent goal
     landmarks (agent.goal_b).  Actions are stored concatenated agent by agent (act_dims); `comm` is
@@ -300,20 +301,25 @@ def rollout_comm(kind, seeds, T):
     keys = ('pos0', 'vel0', 'comm0', 'obs0', 'goal', 'act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info')
     out = {k: [] for k in keys}
     crypto = kind == 'simple_crypto'       # goal rows: (goal_a landmark, landmark whose colour is agent 2's key)
+    wcomm = kind == 'simple_world_comm'    # simple_tag physics + food / forests + a speaking leader; integer info
     for seed in seeds:
         np.random.seed(seed)
         S = COMM[kind].Scenario()
         world = S.make_world()
         _shim(world)
         # benchmark_data is broken (speaker_listener) / absent (reference); simple_crypto has one
-        env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data if crypto else None)
+        env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data if crypto or wcomm else None)
         obs0 = env.reset()
+        if init is not None:
+            init(world, np.random.RandomState(10_000 + seed))
+            obs0 = [env._get_obs(a) for a in env.agents]
         act_dims = [(5 if a.movable else 0) + (0 if a.silent else world.dim_c) for a in world.agents]
         pos0, vel0 = _state(world)
         if crypto:
             out['goal'].append([world.landmarks.index(world.agents[0].goal_a), int(np.argmax(world.agents[2].key))])
         else:
-            out['goal'].append([-1 if a.goal_b is None else world.landmarks.index(a.goal_b) for a in world.agents])
+            out['goal'].append([-1 if getattr(a, 'goal_b', None) is None else world.landmarks.index(a.goal_b)
+                                for a in world.agents])
         out['comm0'].append(np.stack([np.asarray(a.state.c, float) for a in world.agents]))
         arng = np.random.RandomState(40_000 + seed)
         ep = {k: [] for k in ('act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info')}
@@ -329,15 +335,19 @@ def rollout_comm(kind, seeds, T):
             ep['comm'].append(np.stack([np.asarray(a.state.c, float).copy() for a in world.agents]))
             ep['obs'].append(np.concatenate(obs_n))
             ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
-            ep['info'].append(np.stack([np.concatenate(x) for x in info_n['n']]) if crypto else np.zeros((len(act_dims), 0)))
+            ep['info'].append(np.stack([np.concatenate(x) for x in info_n['n']]) if crypto
+                              else np.asarray(info_n['n'], float).reshape(-1, 1) if wcomm else np.zeros((len(act_dims), 0)))
         out['pos0'].append(pos0)
         out['vel0'].append(vel0)
         out['obs0'].append(np.concatenate(obs0))
         for k in ep:
             out[k].append(np.stack(ep[k]))
     res = {k: np.asarray(v) if k == 'goal' else np.stack(v) for k, v in out.items()}
-    if not crypto:
+    if not (crypto or wcomm):
         res.pop('info')
+    if wcomm:
+        res.pop('goal')
+        res['spec_n_food'], res['spec_n_forests'] = np.int64(len(world.food)), np.int64(len(world.forests))
     res['seeds'] = np.asarray(list(seeds))
     res['act_dims'] = np.asarray(act_dims)
     res['spec_dim_c'] = np.int64(world.dim_c)
@@ -432,6 +442,8 @@ def main():
     save('g10_simple_speaker_listener', **rollout_comm('simple_speaker_listener', range(48), 25))
     save('g11_simple_reference', **rollout_comm('simple_reference', range(48), 25))
     save('g12_simple_crypto', **rollout_comm('simple_crypto', range(48), 25))
+    save('g13_simple_world_comm', **rollout_comm('simple_world_comm', range(48), 25))
+    save('g13_simple_world_comm_dense', **rollout_comm('simple_world_comm', range(24), 25, init=dense_init))
     # the fork's leader / follower / super-leader pursuit family
     for name, n in (('L1F2_3Targets_100observe', 32), ('S1L2F2_3Targets_100observe', 32),
                     ('L1F2_3Targets_075observe', 8), ('L1F1_10Targets_wide', 16), ('L1F4_3Targets_wide', 16),

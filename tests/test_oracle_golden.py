@@ -362,3 +362,63 @@ def test_batched_oracle_comm_scenarios_bit_exact(golden_dir, name, mk):
         assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
         if spec.kind == O.SIMPLE_CRYPTO:
             assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1))
+
+
+WORLD_COMM_CASES = ['g13_simple_world_comm', 'g13_simple_world_comm_dense']
+
+
+@pytest.mark.parametrize('name', WORLD_COMM_CASES)
+def test_serial_oracle_world_comm_bit_exact(golden_dir, name):
+    """simple_world_comm: tag physics with a speaking leader, forest visibility masks,
+    food rewards, integer collision info; reset order incl. the second draw of food and forests."""
+    g = _load(golden_dir, name)
+    spec = O.simple_world_comm_spec()
+    assert spec.act_dims == list(g['act_dims']) == [9, 5, 5, 5, 5, 5] and spec.size == list(g['spec_size'])
+    assert spec.collide == list(g['spec_collide']) and spec.silent == list(g['spec_silent'])
+    assert (spec.n_food, spec.n_forests) == (int(g['spec_n_food']), int(g['spec_n_forests']))
+    assert spec.obs_dims == [34] * 4 + [28] * 2 and not g['spec_shared_reward']
+    offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    S, T = g['act'].shape[:2]
+    hidden = 0
+    for s in range(S):
+        np.random.seed(int(g['seeds'][s]))
+        env = O.SerialEnv(spec, benchmark=True)
+        env.reset()
+        obs0 = env.reset()
+        if name.endswith('dense'):                       # the fixture overwrote the state after reset
+            env.set_state(g['pos0'][s], g['vel0'][s])
+            obs0 = [env.observation(i) for i in range(env.n)]
+        else:
+            assert np.array_equal(env.get_state()[0], g['pos0'][s])
+        assert np.array_equal(np.concatenate(obs0), g['obs0'][s])
+        for t in range(T):
+            obs_n, rew_n, _, info_n = env.step([g['act'][s, t, offs[i]:offs[i + 1]] for i in range(spec.n_agents)])
+            pos, vel = env.get_state()
+            assert np.array_equal(pos, g['pos'][s, t]) and np.array_equal(vel, g['vel'][s, t])
+            assert np.array_equal(np.stack([a.comm for a in env.agents]), g['comm'][s, t])
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
+            assert np.array_equal(np.asarray(rew_n, float), g['rew'][s, t]), (name, s, t)
+            assert np.array_equal(np.asarray(info_n['n'], float), g['info'][s, t, :, 0])
+            hidden += int((obs_n[1][14:24] == 0).sum())
+    assert hidden > 0                                    # some agents were hidden by a forest
+
+
+@pytest.mark.parametrize('name', WORLD_COMM_CASES)
+def test_batched_oracle_world_comm_bit_exact(golden_dir, name):
+    g = _load(golden_dir, name)
+    spec = O.simple_world_comm_spec()
+    bo = O.BatchedOracle(spec)
+    S, T = g['act'].shape[:2]
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    obs, _, _ = bo.observe(pos, vel, comm=np.moveaxis(g['comm0'], 0, -1))
+    assert np.array_equal(np.concatenate(obs, 0), g['obs0'].T)
+    for t in range(T):
+        act = g['act'][:, t].T
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)) and np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1))
+        assert np.array_equal(bo.comm_state(act), np.moveaxis(g['comm'][:, t], 0, -1))
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+        assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1))
+
