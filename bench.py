@@ -48,6 +48,7 @@ WORKLOADS = {
     'simple_speaker_listener_2M_f32': ('simple_speaker_listener', {}, 1 << 21, torch.float32),
     'simple_reference_1M_f32': ('simple_reference', {}, 1 << 20, torch.float32),
     'simple_crypto_2M_f32': ('simple_crypto', {}, 1 << 21, torch.float32),
+    'simple_world_comm_1M_f32': ('simple_world_comm', {}, 1 << 20, torch.float32),
 }
 
 

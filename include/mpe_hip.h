@@ -28,7 +28,7 @@
  *                              may be NULL (then not written)
  *         obs  [obs_total][ld]  agent i owns rows [obs_row0(i), obs_row0(i)+obs_dim(i))
  *         rew  [A][ld]
- *         info [A][info_w][ld]  info_w = 1 (simple_tag: collisions), 4 (simple_spread:
+ *         info [A][info_w][ld]  info_w = 1 (simple_tag, simple_world_comm: collisions), 4 (simple_spread:
  *                               rew, collisions, min_dists, occupied_landmarks), L+1
  *                               (simple_adversary: squared distances; the adversary uses column
  *                               0 only) or 0 (simple, simple_push: no benchmark_data); may be NULL
@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 3
+#define MPE_ABI_VERSION 4
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -69,6 +69,9 @@ extern "C" {
                                   one goal landmark per agent (goal_b)                                          */
 #define MPE_SIMPLE_CRYPTO 8    /* build/lib/multiagent/scenarios/simple_crypto.py: adversary, listener, speaker; nobody
                                   moves, everybody speaks; goal rows = (goal landmark, landmark of the speaker's key) */
+
+#define MPE_WORLD_COMM 9       /* build/lib/multiagent/scenarios/simple_world_comm.py: simple_tag roles and physics, a
+                                  speaking leader, food (rewards) and two forests (visibility masks)                 */
 
 /* error codes */
 #define MPE_OK 0
@@ -119,6 +122,11 @@ typedef struct mpe_scenario_desc {
   double obs_r[MPE_MAX_AGENTS];      /* agent.obs_r: observation radius                         */
   uint8_t advfollower[MPE_MAX_AGENTS]; /* agent.advfollower (L1F2_3Targets_100observe.py:40): the
                                           agents whose touch respawns a target (mpe_target_move)   */
+  /* simple_world_comm.py:19-57: world.landmarks = plain landmarks, then n_food food, then n_forests
+     forests (the observation hard-codes two forests, :240-245); 0 for every other kind             */
+  int32_t n_food;
+  int32_t n_forests;
+  uint8_t leader[MPE_MAX_AGENTS];      /* agent.leader (simple_world_comm.py:27,261): sees everybody  */
 } mpe_scenario_desc;
 
 /*
@@ -133,7 +141,7 @@ typedef struct mpe_scenario_desc {
  *                            simple_reference (n_agents rows), (goal, key) of simple_crypto (2 rows); see
  *                            mpe_goal_rows
  *   comm   [A][dim_c][ld]    agent.state.c: written by every world step when not NULL; READ by
- *                            mpe_observe of the speaking stock scenarios (kinds 6-8; required there)
+ *                            mpe_observe of the speaking stock scenarios (kinds 6-9; required there)
  *   lforce [A][2][ld]        agent.leader_force (core.py:156-192): written by every world step,
  *                            read by the HIER_PURSUIT observation; NOT touched by reset (like the
  *                            reference's reset_world).  Required when any forced_id >= 0.

@@ -23,8 +23,9 @@ MPE_HIER_PURSUIT = 5
 MPE_SPEAKER_LISTENER = 6
 MPE_SIMPLE_REFERENCE = 7
 MPE_SIMPLE_CRYPTO = 8
+MPE_WORLD_COMM = 9
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -49,6 +50,8 @@ class ScenarioDesc(C.Structure):
         ('reward_variant', C.c_int32), ('n_target_obs', C.c_int32),
         ('obs_r', C.c_double * MPE_MAX_AGENTS),
         ('advfollower', C.c_uint8 * MPE_MAX_AGENTS),
+        ('n_food', C.c_int32), ('n_forests', C.c_int32),
+        ('leader', C.c_uint8 * MPE_MAX_AGENTS),
     ]
 
 

@@ -386,6 +386,9 @@ class World(object):
             d.advleader[i], d.advsuperleader[i] = int(bool(a.advleader)), int(bool(a.advsuperleader))
             d.obs_r[i] = a.obs_r
             d.advfollower[i] = int(bool(getattr(a, 'advfollower', False)))
+            d.leader[i] = int(bool(getattr(a, 'leader', False)))
+        # simple_world_comm.py:42-57: world.landmarks ends with world.food, then world.forests
+        d.n_food, d.n_forests = len(getattr(self, 'food', ())), len(getattr(self, 'forests', ()))
         _hip.check(_hip.lib.mpe_desc_check(d), 'mpe_desc_check')
         self._desc = d
         return d

@@ -34,6 +34,8 @@ struct DevDesc {
   // fork's command hierarchy (core.py:153-194; L1F*/S1L* scenarios)
   int32_t has_lforce;      // some agent has forced_id >= 0
   int32_t reward_variant, n_target_obs;
+  int32_t n_food, n_forests;            // simple_world_comm: landmarks = plain, food, forests
+  uint32_t leader[MPE_MAX_AGENTS / 32];
   int32_t act_row0[MPE_MAX_AGENTS];  // first action row of each agent (5 rows if movable, + dim_c if not silent)
   int32_t cact_row0[MPE_MAX_AGENTS]; // first comm row inside the action (= act_row0 + 5 for a movable agent)
   uint32_t silent[MPE_MAX_AGENTS / 32];

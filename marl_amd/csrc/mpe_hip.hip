@@ -33,6 +33,12 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
     return 4 + 4 * (A - 1) + (h->forced_id[i] >= 0 ? 2 : 0) + 2 * nt;
   }
   if (h->kind == MPE_SIMPLE_CRYPTO) return h->adversary[i] ? h->dim_c : 2 * h->dim_c;  // simple_crypto.py:153-171
+  if (h->kind == MPE_WORLD_COMM) {  // simple_world_comm.py:305-313
+    int good_others = 0;
+    for (int j = 0; j < A; ++j)
+      if (j != i && !h->adversary[j]) ++good_others;
+    return 4 + 2 * L + 2 * (A - 1) + 2 * good_others + 2 + (h->adversary[i] ? h->dim_c : 0);
+  }
   if (h->kind == MPE_SPEAKER_LISTENER)  // simple_speaker_listener.py:89-94
     return h->movable[i] ? 2 + 2 * L + h->dim_c * (A - 1) : 3;
   if (h->kind == MPE_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + h->dim_c * (A - 1);  // simple_reference.py:89
@@ -46,11 +52,13 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
 
 static bool kind_has_roles(int kind) {
   return kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH ||
-         kind == MPE_HIER_PURSUIT;
+         kind == MPE_HIER_PURSUIT || kind == MPE_WORLD_COMM;
 }
 static bool kind_is_comm(int kind) { return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE; }
 // kinds whose observations contain another agent's state.c (read from the comm buffer when only observing)
-static bool kind_reads_comm(int kind) { return kind_is_comm(kind) || kind == MPE_SIMPLE_CRYPTO; }
+static bool kind_reads_comm(int kind) {
+  return kind_is_comm(kind) || kind == MPE_SIMPLE_CRYPTO || kind == MPE_WORLD_COMM;
+}
 static bool kind_is_ragged(int kind) { return kind == MPE_HIER_PURSUIT || kind_reads_comm(kind); }
 // environment.py:42-76: 5 physical entries for a movable agent, dim_c comm entries for a speaking one
 static int act_dim_of(const mpe_scenario_desc *h, int i) {
@@ -71,6 +79,7 @@ static int info_width_of(const mpe_scenario_desc *h) {
   switch (h->kind) {
     case MPE_SIMPLE_TAG: return 1;
     case MPE_HIER_PURSUIT: return 1;  // L1F2_3Targets_100observe.py:136-148
+    case MPE_WORLD_COMM: return 1;    // simple_world_comm.py:119-127
     case MPE_SIMPLE_SPREAD: return 4;
     case MPE_SIMPLE_ADVERSARY: return h->n_landmarks + 1;  // simple_adversary.py:58-67
     case MPE_SIMPLE_CRYPTO: return 2 * h->dim_c;           // (state.c, goal colour), simple_crypto.py:78-80
@@ -98,7 +107,7 @@ extern "C" const char *mpe_strerror(int code) {
 
 extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   if (!h) return MPE_ERR_NULL;
-  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_SIMPLE_CRYPTO) return MPE_ERR_UNSUPPORTED;
+  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_WORLD_COMM) return MPE_ERR_UNSUPPORTED;
   if (h->n_agents < 1 || h->n_agents > MPE_MAX_AGENTS) return MPE_ERR_DESC;
   if (h->n_landmarks < 0 || h->n_agents + h->n_landmarks > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
   if (h->dim_c < 0 || h->dim_c > 16) return MPE_ERR_DESC;
@@ -145,6 +154,19 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
     if (!h->adversary[0] || h->adversary[1] || h->adversary[2]) return MPE_ERR_DESC;
     for (int a = 0; a < 3; ++a)
       if (h->movable[a] || h->silent[a]) return MPE_ERR_DESC;
+  }
+  if (h->kind == MPE_WORLD_COMM) {
+    // two forests (simple_world_comm.py:240-245), at least one food (min over world.food, :185), and at
+    // least one good agent (min over good agents, :196); everybody moves
+    if (h->n_forests != 2 || h->n_food < 1 || h->n_food + h->n_forests > h->n_landmarks) return MPE_ERR_DESC;
+    int goods = 0;
+    for (int a = 0; a < h->n_agents; ++a) {
+      goods += h->adversary[a] ? 0 : 1;
+      if (!h->movable[a]) return MPE_ERR_DESC;
+    }
+    if (goods < 1) return MPE_ERR_DESC;
+  } else if (h->n_food != 0 || h->n_forests != 0) {
+    return MPE_ERR_DESC;
   }
   if (h->kind == MPE_SIMPLE && h->n_landmarks < 1) return MPE_ERR_DESC;
   if (kind_has_goal(h->kind)) {  // a goal landmark and at least one good agent must exist
@@ -232,6 +254,8 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
   d.has_lforce = has_lforce(h) ? 1 : 0;
   d.reward_variant = h->reward_variant;
   d.n_target_obs = h->n_target_obs;
+  d.n_food = h->n_food;
+  d.n_forests = h->n_forests;
   int row = 0, arow = 0;
   for (int e = 0; e < d.E; ++e) {
     d.size[e] = (T)h->size[e];
@@ -257,6 +281,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     if (h->silent[a]) d.silent[a >> 5] |= 1u << (a & 31);
     if (h->advleader[a]) d.advleader[a >> 5] |= 1u << (a & 31);
     if (h->advsuperleader[a]) d.advsuper[a >> 5] |= 1u << (a & 31);
+    if (h->leader[a]) d.leader[a >> 5] |= 1u << (a & 31);
     d.force_id[a] = h->force_id[a];
     d.forced_id[a] = h->forced_id[a];
     d.obs_r2[a] = (T)h->obs_r[a] * (T)h->obs_r[a];

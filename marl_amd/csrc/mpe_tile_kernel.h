@@ -184,9 +184,71 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
 #else
       if (p.obs != nullptr && active) {
 #endif
+        // simple_world_comm: which agents stand in forest 0 / forest 1 (is_collision, :240-245,258-259)
+        uint64_t in_f0 = 0, in_f1 = 0;
+        if (HIER && d.kind == MPE_WORLD_COMM) {
+          const int f0 = E - 2;
+          const T f0x = sPos[(2 * f0) * TILE + lane], f0y = sPos[(2 * f0 + 1) * TILE + lane];
+          const T f1x = sPos[(2 * f0 + 2) * TILE + lane], f1y = sPos[(2 * f0 + 3) * TILE + lane];
+          for (int a = 0; a < A; ++a) {
+            const T ax = sPos[(2 * a) * TILE + lane], ay = sPos[(2 * a + 1) * TILE + lane];
+            in_f0 |= (uint64_t)touching<T>(ax - f0x, ay - f0y, d.size[a] + d.size[f0]) << a;
+            in_f1 |= (uint64_t)touching<T>(ax - f1x, ay - f1y, d.size[a] + d.size[f0 + 1]) << a;
+          }
+        }
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
+          if (HIER && d.kind == MPE_WORLD_COMM) {
+            // simple_world_comm.py:230-313
+            st_stream(o, sVel[(2 * i) * TILE + lane]);
+            st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+            st_stream(o + 2 * ld, pix);
+            st_stream(o + 3 * ld, piy);
+            o += 4 * ld;
+            for (int l = A; l < E; ++l) {
+              st_stream(o, sPos[(2 * l) * TILE + lane] - pix);
+              st_stream(o + ld, sPos[(2 * l + 1) * TILE + lane] - piy);
+              o += 2 * ld;
+            }
+            const bool i0 = (in_f0 >> i) & 1, i1 = (in_f1 >> i) & 1, lead = bit(d.leader, i);
+            uint64_t vis = 0;  // same forest, or nobody in any forest, or the leader looks (:261)
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              const bool j0 = (in_f0 >> j) & 1, j1 = (in_f1 >> j) & 1;
+              const bool v = (i0 && j0) || (i1 && j1) || (!i0 && !j0 && !i1 && !j1) || lead;
+              vis |= (uint64_t)v << j;
+              st_stream(o, v ? sPos[(2 * j) * TILE + lane] - pix : T(0));
+              st_stream(o + ld, v ? sPos[(2 * j + 1) * TILE + lane] - piy : T(0));
+              o += 2 * ld;
+            }
+            const bool i_adv = bit(d.adversary, i);
+            if (!i_adv) {  // good agents: in_forest before other_vel (:313)
+              st_stream(o, i0 ? T(1) : T(-1));
+              st_stream(o + ld, i1 ? T(1) : T(-1));
+              o += 2 * ld;
+            }
+            for (int j = 0; j < A; ++j) {
+              if (j == i || bit(d.adversary, j)) continue;
+              const bool v = (vis >> j) & 1;
+              st_stream(o, v ? sVel[(2 * j) * TILE + lane] : T(0));
+              st_stream(o + ld, v ? sVel[(2 * j + 1) * TILE + lane] : T(0));
+              o += 2 * ld;
+            }
+            if (i_adv) {   // adversaries: other_vel, in_forest, agent 0's state.c (:292,305-310)
+              st_stream(o, i0 ? T(1) : T(-1));
+              st_stream(o + ld, i1 ? T(1) : T(-1));
+              o += 2 * ld;
+              for (int c = 0; c < d.dim_c; ++c) {
+                T v = T(0);
+                if (!bit(d.silent, 0))
+                  v = DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[0] + c) * ld + env) : p.comm[(int64_t)c * ld + env];
+                st_stream(o, v);
+                o += ld;
+              }
+            }
+            continue;
+          }
           if (HIER && d.kind == MPE_SIMPLE_CRYPTO) {
             // simple_crypto.py:124-171: speaker [goal colour, key]; listener [key, speaker's c]; adversary [speaker's c]
             const int C = d.dim_c;
@@ -411,6 +473,62 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
           }
           if (want_stats && chunk == 0) {
+            const double s_t = group_sum(active ? (double)total : 0.0, TILE);
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
+          }
+        } else if (HIER && d.kind == MPE_WORLD_COMM) {
+          // simple_world_comm.py:119-204.  Every agent's sums are evaluated by the chunk that owns the agent, in
+          // the reference's order (the running reward is not an integer here: -0.1 * min distance comes first).
+          const int food0 = E - d.n_forests - d.n_food, food1 = E - d.n_forests;
+          auto hit = [&](int a, int b) {
+            return touching<T>(sPos[(2 * a) * TILE + lane] - sPos[(2 * b) * TILE + lane],
+                               sPos[(2 * a + 1) * TILE + lane] - sPos[(2 * b + 1) * TILE + lane], d.size[a] + d.size[b]);
+          };
+          auto dist = [&](int a, int b) {
+            return t_sqrt<T>(sqdist<T>(sPos[(2 * a) * TILE + lane], sPos[(2 * a + 1) * TILE + lane],
+                                       sPos[(2 * b) * TILE + lane], sPos[(2 * b + 1) * TILE + lane]));
+          };
+          for (int i = chunk; i < A; i += NCH) {
+            T r_i = T(0);
+            int c_i = 0;
+            if (bit(d.adversary, i)) {
+              T m = T(0);
+              for (int gi = 0; gi < d.n_good; ++gi) {
+                const T dg = dist(d.good_list[gi], i);
+                m = (gi == 0 || dg < m) ? dg : m;
+              }
+              r_i = r_i - T(0.1) * m;
+              if (bit(d.collide, i))
+                for (int gi = 0; gi < d.n_good; ++gi)
+                  for (int ai = 0; ai < d.n_adv; ++ai)
+                    r_i = hit(d.good_list[gi], d.adv_list[ai]) ? r_i + T(5) : r_i;
+              for (int gi = 0; gi < d.n_good; ++gi) c_i += hit(d.good_list[gi], i) ? 1 : 0;
+            } else {
+              if (bit(d.collide, i))
+                for (int ai = 0; ai < d.n_adv; ++ai) r_i = hit(d.adv_list[ai], i) ? r_i - T(5) : r_i;
+              r_i = r_i - T(2) * tag_bound<T>(t_abs<T>(sPos[(2 * i) * TILE + lane]));
+              r_i = r_i - T(2) * tag_bound<T>(t_abs<T>(sPos[(2 * i + 1) * TILE + lane]));
+              T m = T(0);
+              for (int f = food0; f < food1; ++f) {
+                r_i = hit(i, f) ? r_i + T(2) : r_i;
+                const T df = dist(f, i);
+                m = (f == food0 || df < m) ? df : m;
+              }
+              r_i = r_i + T(0.05) * m;
+            }
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, T(c_i));
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              const double s_c = group_sum(active ? (double)c_i : 0.0, TILE);
+              if (lane == 0) { srow[i] += s_r; srow[A + i] += s_c; }
+            }
+          }
+          if (want_stats && chunk == 0) {
+            int total = 0;
+            for (int gi = 0; gi < d.n_good; ++gi)
+              for (int ai = 0; ai < d.n_adv; ++ai) total += hit(d.good_list[gi], d.adv_list[ai]) ? 1 : 0;
             const double s_t = group_sum(active ? (double)total : 0.0, TILE);
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_hip._LIB_PATH)
     for n in names:
         assert hasattr(raw, n), 'libmpe_hip.so does not export %s' % n
-    assert _hip.lib.mpe_abi_version() == 3
+    assert _hip.lib.mpe_abi_version() == _hip.ABI_VERSION == 4
     assert _hip.lib.mpe_desc_sizeof() == ctypes.sizeof(_hip.ScenarioDesc)
 
 
@@ -75,7 +75,7 @@ def test_descriptor_validation_and_error_codes():
     assert lib.mpe_desc_check(bad) == -2
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.n_landmarks = 125
     assert lib.mpe_desc_check(bad) == -2
-    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.kind = 9
+    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.kind = 10
     assert lib.mpe_desc_check(bad) == -5
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.movable[4] = 1
     assert lib.mpe_desc_check(bad) == -5
@@ -265,4 +265,36 @@ def test_simple_crypto_geometry_and_validation():
     assert bytes(w.descriptor()) == bytes(d)
     assert [a.speaker for a in w.agents] == [False, False, True]
     assert sc.good_listeners(w) == [w.agents[1]] and sc.adversaries(w) == [w.agents[0]]
+
+
+def test_simple_world_comm_geometry_and_validation():
+    """simple_world_comm: the leader's action has 5 + dim_c rows, observations 34 / 28 wide, info width 1;
+    the descriptor check pins two forests, some food and a good agent."""
+    from marl_amd import _hip
+    import marl_amd.scenarios as scenarios
+    lib = _hip.lib
+    spec = O.simple_world_comm_spec()
+    d = _desc(spec)
+    assert lib.mpe_desc_check(d) == 0
+    assert [lib.mpe_act_dim(d, i) for i in range(6)] == spec.act_dims == [9, 5, 5, 5, 5, 5]
+    assert [lib.mpe_obs_dim(d, i) for i in range(6)] == spec.obs_dims == [34] * 4 + [28] * 2
+    assert lib.mpe_goal_rows(d) == 0 and lib.mpe_info_width(d) == 1 and lib.mpe_stats_width(d) == 14
+    for field, val in (('n_forests', 1), ('n_food', 0), ('n_food', 4)):
+        bad = _hip.ScenarioDesc.from_buffer_copy(d)
+        setattr(bad, field, val)
+        assert lib.mpe_desc_check(bad) == -2, field
+    bad = _hip.ScenarioDesc.from_buffer_copy(d)
+    bad.adversary[4] = bad.adversary[5] = 1
+    assert lib.mpe_desc_check(bad) == -2                      # nobody to chase
+    bad = _hip.ScenarioDesc.from_buffer_copy(_desc(O.simple_tag_spec()))
+    bad.n_food = 1
+    assert lib.mpe_desc_check(bad) == -2                      # food / forests belong to simple_world_comm only
+    b = _hip.Buffers()
+    b.pos, b.vel, b.obs = 8, 8, 8
+    assert lib.mpe_observe_f64(d, 4, 4, b, None) == -1        # observing needs the leader's state.c (comm)
+    sc = scenarios.load('simple_world_comm.py').Scenario()
+    sc._finish_world = lambda world: world
+    w = sc.make_world()
+    assert bytes(w.descriptor()) == bytes(d)
+    assert [l.name for l in w.landmarks] == ['landmark 0', 'food 0', 'food 1', 'forest 0', 'forest 1']
 
