@@ -8,6 +8,7 @@
 
 #include "mpe_device.h"
 #include "mpe_comm_kernel.h"
+#include "mpe_wcomm_kernel.h"
 #include "mpe_hier_kernel.h"
 #include "mpe_small_kernel.h"
 #include "mpe_tile_kernel.h"
@@ -312,8 +313,22 @@ enum SmallId {
   // speaking stock scenarios (mpe_comm_kernel.h)
   COMM_SPEAKER_LISTENER,
   COMM_REFERENCE,
-  COMM_CRYPTO
+  COMM_CRYPTO,
+  WCOMM_4_2_1_2_2  // simple_world_comm (mpe_wcomm_kernel.h)
 };
+
+// Stock shape of simple_world_comm (mpe_wcomm_kernel.h header), or SMALL_NONE.
+static SmallId wcomm_variant(const mpe_scenario_desc *h) {
+  const int A = 6, L = 5;
+  if (h->n_agents != A || h->n_landmarks != L || h->n_food != 2 || h->n_forests != 2 || h->dim_c != 4) return SMALL_NONE;
+  for (int a = 0; a < A; ++a) {
+    if ((h->adversary[a] != 0) != (a < 4) || (h->silent[a] != 0) != (a > 0)) return SMALL_NONE;
+    if (!(h->max_speed[a] >= 0.0) || h->u_noise[a] != 0.0) return SMALL_NONE;
+  }
+  for (int e = 0; e < A + L; ++e)
+    if ((h->collide[e] != 0) != (e < A + 1)) return SMALL_NONE;
+  return WCOMM_4_2_1_2_2;
+}
 
 // Stock shape of simple_speaker_listener / simple_reference (mpe_comm_kernel.h header), or SMALL_NONE.
 static SmallId comm_variant(const mpe_scenario_desc *h) {
@@ -366,6 +381,7 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
     case MPE_SPEAKER_LISTENER:
     case MPE_SIMPLE_REFERENCE: return comm_variant(h);
     case MPE_SIMPLE_CRYPTO: return h->dim_c == 4 ? COMM_CRYPTO : SMALL_NONE;  // roles, shape: mpe_desc_check
+    case MPE_WORLD_COMM: return wcomm_variant(h);
     default: return SMALL_NONE;
   }
   for (int a = 0; a < A; ++a) {
@@ -447,6 +463,11 @@ static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStrea
       case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
       case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
       case COMM_REFERENCE: return launch_comm<T, MPE_SIMPLE_REFERENCE, 10, DO_STEP, DO_OBS>(p, s);
+      case WCOMM_4_2_1_2_2: {
+        const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+        hipLaunchKernelGGL((wcomm_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
       case COMM_CRYPTO: {
         const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
         hipLaunchKernelGGL((crypto_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
