@@ -42,6 +42,7 @@ SPEAKER_LISTENER = 6   # build/lib/multiagent/scenarios/simple_speaker_listener.
 SIMPLE_REFERENCE = 7   # build/lib/multiagent/scenarios/simple_reference.py
 SIMPLE_CRYPTO = 8      # build/lib/multiagent/scenarios/simple_crypto.py (nobody moves: messages only)
 WORLD_COMM = 9         # build/lib/multiagent/scenarios/simple_world_comm.py (tag physics, food, forests, a speaking leader)
+HIER_MOVING = 10       # multiagent/scenarios/{L1F4,S1L2F4}_MovingTarget.py: the command hierarchy chasing a moving prey
 COMM_KINDS = (SPEAKER_LISTENER, SIMPLE_REFERENCE)   # per-agent goal landmark (agent.goal_b) + observed comm
 # landmark.color tables (simple_speaker_listener.py:48-50 / simple_reference.py:41-43): (base, highlighted)
 COMM_COLORS = {SPEAKER_LISTENER: (0.15, 0.65), SIMPLE_REFERENCE: (0.25, 0.75)}
@@ -103,7 +104,7 @@ class ScenarioSpec:
         if self.leader is None:
             self.leader = [False] * A
         if self.advfollower is None:                 # L1F2_3Targets_100observe.py:40,52,64: the silent adversaries
-            self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind == HIER_PURSUIT
+            self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind in (HIER_PURSUIT, HIER_MOVING)
                                 for i in range(A)]
 
     def act_dim(self, i):
@@ -113,6 +114,14 @@ class ScenarioSpec:
     def comm_row0(self, i):
         """First comm entry inside agent i's action (after the physical part, if it has one)."""
         return 5 if self.movable[i] else 0
+
+    def observes_leader_force(self, i):
+        """HIER_MOVING: does agent i's observation end with its leader_force?  L1F4_MovingTarget.py:252-258
+        (variant 0): forced_id >= 0.  S1L2F4_MovingTarget.py:254-260 (variant 1): every agent has the
+        attribute (core.py:156), and the ones that are neither advleader nor good return it."""
+        if self.reward_variant == 0:
+            return self.forced_id[i] >= 0
+        return not (self.advleader[i] or not self.adversary[i])
 
     @property
     def goal_rows(self):
@@ -143,6 +152,8 @@ class ScenarioSpec:
             return 4 + 2 * L + 2 * (A - 1) + 2 * n_good_others
         if self.kind == HIER_PURSUIT:           # L1F2_3Targets_100observe.py:250-253
             return 4 + 4 * (A - 1) + (2 if self.forced_id[i] >= 0 else 0) + 2 * min(L, self.n_target_obs)
+        if self.kind == HIER_MOVING:            # L1F4_MovingTarget.py:252-258 / S1L2F4_MovingTarget.py:254-260
+            return 4 + 4 * (A - 1) + (2 if self.observes_leader_force(i) else 0)
         if self.kind == SPEAKER_LISTENER:       # simple_speaker_listener.py:89-94
             return 3 if not self.movable[i] else 2 + 2 * L + self.dim_c * (A - 1)
         if self.kind == SIMPLE_REFERENCE:       # simple_reference.py:89
@@ -172,7 +183,7 @@ class ScenarioSpec:
             return 2 * self.dim_c
         if self.kind in (SIMPLE, SIMPLE_PUSH) + COMM_KINDS:  # no (working) benchmark_data in these scenarios
             return 0
-        return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT, WORLD_COMM) else 4
+        return 1 if self.kind in (SIMPLE_TAG, HIER_PURSUIT, WORLD_COMM, HIER_MOVING) else 4
 
 
 def simple_tag_spec(n_adv=3, n_good=1, n_landmarks=2, u_noise=None):
@@ -209,7 +220,8 @@ def hier_spec_from_golden(g):
     A = int(g['spec_n_agents'])
     E = len(g['spec_size'])
     return ScenarioSpec(
-        kind=HIER_PURSUIT, n_agents=A, n_landmarks=E - A, adversary=[bool(x) for x in g['spec_adversary']],
+        kind=HIER_MOVING if ('spec_moving_target' in g.files and bool(g['spec_moving_target'])) else HIER_PURSUIT,
+        n_agents=A, n_landmarks=E - A, adversary=[bool(x) for x in g['spec_adversary']],
         size=[float(x) for x in g['spec_size']], accel=[float(x) for x in g['spec_accel']],
         max_speed=[float(x) for x in g['spec_max_speed']], collide=[bool(x) for x in g['spec_collide']],
         movable=[bool(x) for x in g['spec_movable']], u_noise=[None] * A, mass=[1.0] * E,
@@ -532,6 +544,60 @@ class SerialEnv:
             r -= pen
         return r
 
+    # -- *_MovingTarget gathers (L1F4_MovingTarget.py:157-258; S1L2F4_MovingTarget.py differs in :227,254,257) --
+    def _moving_observation(self, i):
+        me, s = self.agents[i], self.spec
+        other_pos, other_vel = [], []
+        for other in self.agents:
+            if other is me:
+                continue
+            dis = np.sqrt(np.sum(np.square(other.pos - me.pos)))
+            if me.adversary:
+                linked = ((me.force_id >= 0 and me.force_id == other.forced_id)
+                          or (me.forced_id >= 0 and me.forced_id == other.force_id))
+                if dis < me.obs_r or (s.reward_variant == 0 and linked):
+                    other_pos.append(other.pos - me.pos)
+                    other_vel.append(other.vel)
+                else:
+                    other_pos.append(np.array([0, 0]))
+                    other_vel.append(np.array([0, 0]))
+            else:                                # the prey sees everybody, in ABSOLUTE coordinates (:249-251)
+                other_pos.append(other.pos)
+                other_vel.append(other.vel)
+        comm = [me.leader_force] if s.observes_leader_force(i) else []
+        return np.concatenate([me.vel] + [me.pos] + other_pos + other_vel + comm)
+
+    def _moving_reward(self, i):
+        me = self.agents[i]
+        rew = 0
+        if me.adversary:                         # :186-212: the same contact sum for every adversary
+            count = 0
+            for a in self.agents:
+                if a.adversary:
+                    continue
+                for other in self.agents:
+                    if other is a:
+                        continue
+                    if self._touching(a, other):
+                        count += 1
+                        rew += 10
+                if count >= 4:
+                    rew += 50
+        elif me.collide:                         # :162-171
+            for a in self.agents:
+                if a.adversary and self._touching(a, me):
+                    rew -= 1
+        for p in range(2):
+            x = abs(me.pos[p])
+            if x < 0.9:
+                pen = 0
+            elif x < 1.0:
+                pen = (x - 0.9) * 10
+            else:
+                pen = min(np.exp(2 * x - 2), 10)
+            rew -= pen
+        return rew
+
     def _hier_info(self, i):                    # L1F2_3Targets_100observe.py:136-148
         me = self.agents[i]
         return sum(1 for a in self.agents if a.adversary != me.adversary and self._touching(a, me))
@@ -561,6 +627,8 @@ class SerialEnv:
         kind = self.spec.kind
         if kind == HIER_PURSUIT:
             return self._hier_observation(i)
+        if kind == HIER_MOVING:
+            return self._moving_observation(i)
         if kind == SIMPLE_CRYPTO:                                # simple_crypto.py:124-171
             onehot = lambda k: np.eye(self.spec.dim_c)[k]        # landmark.color = one-hot (:55-59)
             goal_color, key = onehot(self.goals[0]), onehot(self.goals[1])
@@ -638,6 +706,8 @@ class SerialEnv:
         kind = self.spec.kind
         if kind == HIER_PURSUIT:
             return self._hier_reward(i)
+        if kind == HIER_MOVING:
+            return self._moving_reward(i)
         if kind == SIMPLE_CRYPTO:                                # simple_crypto.py:94-121
             goal_color = np.eye(self.spec.dim_c)[self.goals[0]]
             zero = np.zeros(self.spec.dim_c)
@@ -742,7 +812,7 @@ class SerialEnv:
 
     def info(self, i):
         me = self.agents[i]
-        if self.spec.kind == HIER_PURSUIT:
+        if self.spec.kind in (HIER_PURSUIT, HIER_MOVING):
             return self._hier_info(i)
         if self.spec.kind == SIMPLE_CRYPTO:                      # simple_crypto.py:78-80
             return np.concatenate([me.comm, np.eye(self.spec.dim_c)[self.goals[0]]])
@@ -966,6 +1036,67 @@ class BatchedOracle:
         info = np.stack([np.concatenate([comm[i], gcol], 0) for i in range(3)])
         return obs, rew, info
 
+    def _observe_moving(self, pos, vel, lforce):
+        """*_MovingTarget gathers, vectorised (L1F4_MovingTarget.py:128-258)."""
+        s, T = self.spec, self.dt
+        A = s.n_agents
+        B = pos.shape[-1]
+        dist = lambda e, f: self._dist(pos, e, f)
+        obs, rew, info = [], np.zeros((A, B), T), np.zeros((A, 1, B), T)
+        goods = [a for a in range(A) if not s.adversary[a]]
+        with np.errstate(all='ignore'):
+            touch = lambda e, f: dist(e, f) < T(s.size[e] + s.size[f])
+            adv_r = np.zeros(B, T)
+            count = np.zeros(B, np.int64)
+            for a in goods:
+                for o in range(A):
+                    if o == a:
+                        continue
+                    h = touch(a, o)
+                    count = count + h
+                    adv_r = adv_r + T(10) * h
+                adv_r = adv_r + T(50) * (count >= 4)
+            for i in range(A):
+                rows = [vel[i], pos[i]]
+                vis = []
+                for j in range(A):
+                    if j == i:
+                        continue
+                    if s.adversary[i]:
+                        linked = ((s.force_id[i] >= 0 and s.force_id[i] == s.forced_id[j])
+                                  or (s.forced_id[i] >= 0 and s.forced_id[i] == s.force_id[j]))
+                        v = dist(j, i) < T(s.obs_r[i])
+                        if s.reward_variant == 0 and linked:
+                            v = np.ones(B, bool)
+                        rows.append(np.where(v, pos[j] - pos[i], T(0)))
+                    else:
+                        v = np.ones(B, bool)
+                        rows.append(pos[j])
+                    vis.append((j, v))
+                rows += [np.where(v, vel[j], T(0)) for j, v in vis]
+                if s.observes_leader_force(i):
+                    rows.append(lforce[i])
+                obs.append(np.concatenate(rows, axis=0))
+                if s.adversary[i]:
+                    r = adv_r.copy()
+                else:
+                    r = np.zeros(B, T)
+                    if s.collide[i]:
+                        for a in range(A):
+                            if s.adversary[a]:
+                                r = r - touch(a, i)
+                for p in range(2):
+                    x = np.abs(pos[i, p])
+                    bnd = np.where(x < T(0.9), T(0),
+                                   np.where(x < T(1.0), (x - T(0.9)) * T(10),
+                                            np.minimum(np.exp(T(2) * x - T(2)), T(10))))
+                    r = r - bnd
+                rew[i] = r
+                for a in range(A):
+                    if s.adversary[a] != s.adversary[i]:
+                        info[i, 0] += touch(a, i)
+        return obs, rew, info
+
     def _observe_hier(self, pos, vel, lforce):
         """L1F*/S1L* gathers, vectorised (e.g. L1F2_3Targets_100observe.py:136-253)."""
         s, T = self.spec, self.dt
@@ -1176,9 +1307,9 @@ class BatchedOracle:
         B = pos.shape[-1]
         pos = np.asarray(pos, dtype=T)
         vel = np.asarray(vel, dtype=T)
-        if s.kind == HIER_PURSUIT:
+        if s.kind in (HIER_PURSUIT, HIER_MOVING):
             lforce = np.zeros((A, 2, B), T) if lforce is None else np.asarray(lforce, T)
-            obs, rew, info = self._observe_hier(pos, vel, lforce)
+            obs, rew, info = (self._observe_hier if s.kind == HIER_PURSUIT else self._observe_moving)(pos, vel, lforce)
             return obs, rew, (info if want_info else None)
         if s.kind in (SIMPLE, SIMPLE_ADVERSARY, SIMPLE_PUSH):
             obs, rew, info = self._observe_f1(pos, vel, goal)

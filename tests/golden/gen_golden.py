@@ -114,7 +114,8 @@ def rollout_hier(name, seeds, T, init=None, actions='rand'):
             init(world, np.random.RandomState(10_000 + seed))
             obs0 = [env._get_obs(a) for a in env.agents]
         pos0, vel0 = _state(world)
-        out['lforce0'].append(np.stack([np.asarray(a.leader_force, float) for a in world.agents]))
+        # the prey of the *_MovingTarget files has no leader_force until the first World.step (core.py:156)
+        out['lforce0'].append(np.stack([np.asarray(getattr(a, 'leader_force', np.zeros(2)), float) for a in world.agents]))
         arng = np.random.RandomState(20_000 + seed)
         ep = {k: [] for k in ('act', 'pos', 'vel', 'lforce', 'obs', 'rew', 'info')}
         for t in range(T):
@@ -163,7 +164,8 @@ def rollout_hier(name, seeds, T, init=None, actions='rand'):
     res['spec_advleader'] = np.array([bool(a.advleader) for a in ags])
     res['spec_advsuperleader'] = np.array([bool(a.advsuperleader) for a in ags])
     res['spec_obs_r'] = np.array([a.obs_r for a in ags], float)
-    res['spec_reward_variant'] = np.int64(1 if 'rewardFixed' in name else 0)
+    res['spec_reward_variant'] = np.int64(1 if 'rewardFixed' in name or name == 'S1L2F4_MovingTarget' else 0)
+    res['spec_moving_target'] = np.bool_('MovingTarget' in name)
     return res
 
 
@@ -366,6 +368,12 @@ def dense_init(world, rng):
         a.state.p_vel = rng.uniform(-0.5, 0.5, 2)
 
 
+def crowd_init(world, rng):
+    """Everybody on top of everybody: fires the count >= 4 bonus of the *_MovingTarget reward."""
+    for e in world.entities:
+        e.state.p_pos = rng.uniform(-0.03, 0.03, 2)
+
+
 def oob_init(world, rng):
     mags = [0.85, 0.95, 1.5, 2.5]
     for a in world.agents:
@@ -450,6 +458,11 @@ def main():
                     ('S1L2F2_10Targets_wide', 16), ('S1L2F2_10Targets_wide_rewardFixed', 16)):
         save('h_' + name, **rollout_hier(name, range(n), 25, actions='softmax'))
         save('h_' + name + '_dense', **rollout_hier(name, range(n // 2), 25, init=dense_init))
+    # the two *_MovingTarget files: a moving prey instead of landmarks, own reward / observation text
+    for name in ('L1F4_MovingTarget', 'S1L2F4_MovingTarget'):
+        save('m_' + name, **rollout_hier(name, range(24), 25, actions='softmax'))
+        save('m_' + name + '_dense', **rollout_hier(name, range(24), 25, init=dense_init))
+        save('m_' + name + '_crowd', **rollout_hier(name, range(16), 6, init=crowd_init))
     kat_cases()
 
 

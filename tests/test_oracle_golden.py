@@ -101,7 +101,10 @@ HIER_CASES = ['h_L1F2_3Targets_100observe', 'h_L1F2_3Targets_100observe_dense',
               'h_L1F1_10Targets_wide', 'h_L1F1_10Targets_wide_dense',
               'h_L1F4_3Targets_wide', 'h_L1F4_3Targets_wide_dense',
               'h_S1L2F2_10Targets_wide', 'h_S1L2F2_10Targets_wide_dense',
-              'h_S1L2F2_10Targets_wide_rewardFixed', 'h_S1L2F2_10Targets_wide_rewardFixed_dense']
+              'h_S1L2F2_10Targets_wide_rewardFixed', 'h_S1L2F2_10Targets_wide_rewardFixed_dense',
+              # the *_MovingTarget files: a moving prey instead of landmarks, own observation / reward text
+              'm_L1F4_MovingTarget', 'm_L1F4_MovingTarget_dense', 'm_L1F4_MovingTarget_crowd',
+              'm_S1L2F4_MovingTarget', 'm_S1L2F4_MovingTarget_dense', 'm_S1L2F4_MovingTarget_crowd']
 
 
 def _split_actions(g, s, t):
@@ -168,6 +171,23 @@ def test_hier_goldens_exercise_the_branches(golden_dir):
     g = _load(golden_dir, 'h_S1L2F2_10Targets_wide_rewardFixed')
     r = g['rew'][:, :, 4]           # is_observed() compares a target with itself: constant +1 per (target, leader)
     assert r.max() == 20.0 and (r <= 20.0).all() and (r == 20.0).mean() > 0.5
+
+
+def test_moving_target_goldens_exercise_the_branches(golden_dir):
+    for name in ('m_L1F4_MovingTarget_crowd', 'm_S1L2F4_MovingTarget_crowd'):
+        g = _load(golden_dir, name)
+        assert (g['rew'][:, :, 0] >= 89).any()                            # count >= 4: the +50 bonus
+        assert (g['rew'][:, :, -1] <= -3).any()                           # the prey pays 1 per touching adversary
+    g = _load(golden_dir, 'm_S1L2F4_MovingTarget')
+    spec = O.hier_spec_from_golden(g)
+    assert spec.kind == O.HIER_MOVING and spec.reward_variant == 1
+    assert spec.obs_dims == [34] * 4 + [32] * 4                           # only the followers observe leader_force
+    assert (g['obs'][:, :, 4:18] == 0).any() and (g['obs'][:, :, 4:18] != 0).any()
+    g = _load(golden_dir, 'm_L1F4_MovingTarget')
+    spec = O.hier_spec_from_golden(g)
+    assert spec.reward_variant == 0 and spec.obs_dims == [26] * 4 + [24] * 2 and spec.dim_c == 3
+    prey = g['obs'][:, :, sum(spec.obs_dims[:5]):]                        # absolute positions of the others
+    assert np.array_equal(prey[:, :, 4:6], g['pos'][:, :, 0])
 
 
 def test_golden_cases_exercise_the_branches(golden_dir):
