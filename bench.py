@@ -49,6 +49,8 @@ WORKLOADS = {
     'simple_reference_1M_f32': ('simple_reference', {}, 1 << 20, torch.float32),
     'simple_crypto_2M_f32': ('simple_crypto', {}, 1 << 21, torch.float32),
     'simple_world_comm_1M_f32': ('simple_world_comm', {}, 1 << 20, torch.float32),
+    'L1F4_MovingTarget_1M_f32': ('L1F4_MovingTarget', {}, 1 << 20, torch.float32),
+    'S1L2F4_MovingTarget_1M_f32': ('S1L2F4_MovingTarget', {}, 1 << 20, torch.float32),
 }
 
 

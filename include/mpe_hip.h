@@ -73,6 +73,11 @@ extern "C" {
 #define MPE_WORLD_COMM 9       /* build/lib/multiagent/scenarios/simple_world_comm.py: simple_tag roles and physics, a
                                   speaking leader, food (rewards) and two forests (visibility masks)                 */
 
+#define MPE_HIER_MOVING 10     /* multiagent/scenarios/L1F4_MovingTarget.py, S1L2F4_MovingTarget.py: the command hierarchy
+                                  chasing a moving prey (no landmarks); reward_variant 0 = the L1F4 file's observation
+                                  text (command links are visible, forced agents observe leader_force), 1 = the S1L2F4
+                                  file's (radius only; agents that are neither advleader nor good observe it)        */
+
 /* error codes */
 #define MPE_OK 0
 #define MPE_ERR_NULL (-1)        /* a required pointer is NULL                       */
@@ -117,7 +122,8 @@ typedef struct mpe_scenario_desc {
   uint8_t advleader[MPE_MAX_AGENTS];
   uint8_t advsuperleader[MPE_MAX_AGENTS]; /* its command is the raw c[0:2], observed not applied
                                              (core.py:162-163)                                  */
-  int32_t reward_variant;            /* 0: L1F.. / S1L.. default; 1: S1L2F2_10Targets_wide_rewardFixed */
+  int32_t reward_variant;            /* 0: L1F.. / S1L.. default; 1: S1L2F2_10Targets_wide_rewardFixed;
+                                        MPE_HIER_MOVING: 0 = L1F4_MovingTarget, 1 = S1L2F4_MovingTarget   */
   int32_t n_target_obs;              /* target_pos[0:n] in the observation (3)                  */
   double obs_r[MPE_MAX_AGENTS];      /* agent.obs_r: observation radius                         */
   uint8_t advfollower[MPE_MAX_AGENTS]; /* agent.advfollower (L1F2_3Targets_100observe.py:40): the

@@ -24,6 +24,7 @@ MPE_SPEAKER_LISTENER = 6
 MPE_SIMPLE_REFERENCE = 7
 MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
+MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
 ABI_VERSION = 4
 

@@ -35,6 +35,8 @@ struct DevDesc {
   int32_t has_lforce;      // some agent has forced_id >= 0
   int32_t reward_variant, n_target_obs;
   int32_t n_food, n_forests;            // simple_world_comm: landmarks = plain, food, forests
+  uint32_t obs_lf[MPE_MAX_AGENTS / 32]; // agents whose observation carries their leader_force
+  T obs_r[MPE_MAX_AGENTS];              // observation radius (the *_MovingTarget files compare distances, not squares)
   uint32_t leader[MPE_MAX_AGENTS / 32];
   int32_t act_row0[MPE_MAX_AGENTS];  // first action row of each agent (5 rows if movable, + dim_c if not silent)
   int32_t cact_row0[MPE_MAX_AGENTS]; // first comm row inside the action (= act_row0 + 5 for a movable agent)

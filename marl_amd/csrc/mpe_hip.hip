@@ -21,6 +21,14 @@ static_assert(sizeof(KParams<double>) <= 8192, "kernarg segment must stay under 
 // ------------------------------------------------------------------------------------------------
 // descriptor helpers (host)
 // ------------------------------------------------------------------------------------------------
+// Does agent i's observation end with its leader_force?  L1F*/S1L* Targets files and L1F4_MovingTarget.py:252:
+// forced_id >= 0.  S1L2F4_MovingTarget.py:254-257: hasattr(agent, 'leader_force') holds for every agent
+// (core.py:156) and the agents that are neither advleader nor good return it.
+static bool observes_lforce(const mpe_scenario_desc *h, int i) {
+  if (h->kind == MPE_HIER_MOVING && h->reward_variant == 1) return !h->advleader[i] && h->adversary[i];
+  return (h->kind == MPE_HIER_PURSUIT || h->kind == MPE_HIER_MOVING) && h->forced_id[i] >= 0;
+}
+
 static int obs_dim_of(const mpe_scenario_desc *h, int i) {
   const int A = h->n_agents, L = h->n_landmarks;
   if (h->kind == MPE_SIMPLE_TAG) {  // simple_tag.py:147
@@ -33,6 +41,8 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
     const int nt = L < h->n_target_obs ? L : h->n_target_obs;
     return 4 + 4 * (A - 1) + (h->forced_id[i] >= 0 ? 2 : 0) + 2 * nt;
   }
+  if (h->kind == MPE_HIER_MOVING)  // L1F4_MovingTarget.py:252-258 / S1L2F4_MovingTarget.py:254-260
+    return 4 + 4 * (A - 1) + (observes_lforce(h, i) ? 2 : 0);
   if (h->kind == MPE_SIMPLE_CRYPTO) return h->adversary[i] ? h->dim_c : 2 * h->dim_c;  // simple_crypto.py:153-171
   if (h->kind == MPE_WORLD_COMM) {  // simple_world_comm.py:305-313
     int good_others = 0;
@@ -53,14 +63,15 @@ static int obs_dim_of(const mpe_scenario_desc *h, int i) {
 
 static bool kind_has_roles(int kind) {
   return kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_ADVERSARY || kind == MPE_SIMPLE_PUSH ||
-         kind == MPE_HIER_PURSUIT || kind == MPE_WORLD_COMM;
+         kind == MPE_HIER_PURSUIT || kind == MPE_WORLD_COMM || kind == MPE_HIER_MOVING;
 }
 static bool kind_is_comm(int kind) { return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE; }
 // kinds whose observations contain another agent's state.c (read from the comm buffer when only observing)
 static bool kind_reads_comm(int kind) {
   return kind_is_comm(kind) || kind == MPE_SIMPLE_CRYPTO || kind == MPE_WORLD_COMM;
 }
-static bool kind_is_ragged(int kind) { return kind == MPE_HIER_PURSUIT || kind_reads_comm(kind); }
+static bool kind_is_hier(int kind) { return kind == MPE_HIER_PURSUIT || kind == MPE_HIER_MOVING; }
+static bool kind_is_ragged(int kind) { return kind_is_hier(kind) || kind_reads_comm(kind); }
 // environment.py:42-76: 5 physical entries for a movable agent, dim_c comm entries for a speaking one
 static int act_dim_of(const mpe_scenario_desc *h, int i) {
   return (h->movable[i] ? 5 : 0) + (h->silent[i] ? 0 : h->dim_c);
@@ -81,6 +92,7 @@ static int info_width_of(const mpe_scenario_desc *h) {
     case MPE_SIMPLE_TAG: return 1;
     case MPE_HIER_PURSUIT: return 1;  // L1F2_3Targets_100observe.py:136-148
     case MPE_WORLD_COMM: return 1;    // simple_world_comm.py:119-127
+    case MPE_HIER_MOVING: return 1;   // L1F4_MovingTarget.py:128-140
     case MPE_SIMPLE_SPREAD: return 4;
     case MPE_SIMPLE_ADVERSARY: return h->n_landmarks + 1;  // simple_adversary.py:58-67
     case MPE_SIMPLE_CRYPTO: return 2 * h->dim_c;           // (state.c, goal colour), simple_crypto.py:78-80
@@ -108,7 +120,7 @@ extern "C" const char *mpe_strerror(int code) {
 
 extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   if (!h) return MPE_ERR_NULL;
-  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_WORLD_COMM) return MPE_ERR_UNSUPPORTED;
+  if (h->kind < MPE_SIMPLE_TAG || h->kind > MPE_HIER_MOVING) return MPE_ERR_UNSUPPORTED;
   if (h->n_agents < 1 || h->n_agents > MPE_MAX_AGENTS) return MPE_ERR_DESC;
   if (h->n_landmarks < 0 || h->n_agents + h->n_landmarks > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
   if (h->dim_c < 0 || h->dim_c > 16) return MPE_ERR_DESC;
@@ -126,7 +138,7 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   for (int a = 0; a < h->n_agents; ++a) {
     if (h->force_id[a] < -1 || h->forced_id[a] < -1) return MPE_ERR_DESC;
     // commands exist in the hierarchy scenarios only (no stock scenario sets force_id / forced_id)
-    if ((h->force_id[a] >= 0 || h->forced_id[a] >= 0) && h->kind != MPE_HIER_PURSUIT) return MPE_ERR_UNSUPPORTED;
+    if ((h->force_id[a] >= 0 || h->forced_id[a] >= 0) && !kind_is_hier(h->kind)) return MPE_ERR_UNSUPPORTED;
     if (!(h->obs_r[a] >= 0.0) || !std::isfinite(h->obs_r[a])) return MPE_ERR_DESC;
     // comm entries are consumed by the command hierarchy only; the stock scenarios that observe
     // other.state.c (simple_spread.py:95) are built silent (simple_spread.py:17)
@@ -141,6 +153,7 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
     if (h->n_target_obs < 0 || h->n_target_obs > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
     if (h->reward_variant != 0 && h->reward_variant != 1) return MPE_ERR_DESC;
   }
+  if (h->kind == MPE_HIER_MOVING && h->reward_variant != 0 && h->reward_variant != 1) return MPE_ERR_DESC;
   if (kind_is_comm(h->kind)) {
     // two agents, three coloured landmarks (simple_speaker_listener.py:16,48-50 / simple_reference.py:11,41-43)
     if (h->n_agents != 2 || h->n_landmarks != 3 || h->dim_c < 1) return MPE_ERR_DESC;
@@ -286,6 +299,8 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     d.force_id[a] = h->force_id[a];
     d.forced_id[a] = h->forced_id[a];
     d.obs_r2[a] = (T)h->obs_r[a] * (T)h->obs_r[a];
+    d.obs_r[a] = (T)h->obs_r[a];
+    if (observes_lforce(h, a)) d.obs_lf[a >> 5] |= 1u << (a & 31);
   }
   d.obs_total = row;
   int ncol = 0;

@@ -303,6 +303,43 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             continue;
           }
+          if (HIER && d.kind == MPE_HIER_MOVING) {
+            // L1F4_MovingTarget.py:214-258 (S1L2F4_MovingTarget.py: radius only, :227)
+            st_stream(o, sVel[(2 * i) * TILE + lane]);
+            st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
+            st_stream(o + 2 * ld, pix);
+            st_stream(o + 3 * ld, piy);
+            o += 4 * ld;
+            const bool i_adv = bit(d.adversary, i);
+            const T rad = d.obs_r[i];
+            const int fi = d.force_id[i], fdi = d.forced_id[i];
+            uint64_t vis = 0;
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              const T pjx = sPos[(2 * j) * TILE + lane], pjy = sPos[(2 * j + 1) * TILE + lane];
+              const T dx = pjx - pix, dy = pjy - piy;
+              const bool linked = d.reward_variant == 0 &&
+                                  ((fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]));
+              const bool v = !i_adv || linked || t_sqrt<T>(dx * dx + dy * dy) < rad;
+              vis |= (uint64_t)v << j;
+              // the prey sees everybody, in absolute coordinates (:249-251)
+              st_stream(o, i_adv ? (v ? dx : T(0)) : pjx);
+              st_stream(o + ld, i_adv ? (v ? dy : T(0)) : pjy);
+              o += 2 * ld;
+            }
+            for (int j = 0; j < A; ++j) {
+              if (j == i) continue;
+              const bool v = (vis >> j) & 1;
+              st_stream(o, v ? sVel[(2 * j) * TILE + lane] : T(0));
+              st_stream(o + ld, v ? sVel[(2 * j + 1) * TILE + lane] : T(0));
+              o += 2 * ld;
+            }
+            if (bit(d.obs_lf, i)) {
+              st_stream(o, sLf[(2 * i) * TILE + lane]);
+              st_stream(o + ld, sLf[(2 * i + 1) * TILE + lane]);
+            }
+            continue;
+          }
           if (HIER && d.kind == MPE_HIER_PURSUIT) {
             // L1F2_3Targets_100observe.py:198-253 (same text in every L1F*/S1L* file)
             st_stream(o, sVel[(2 * i) * TILE + lane]);
@@ -593,6 +630,45 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           if (want_stats && chunk == 0) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) srow[2 * A + 1] += s_n;
+          }
+        } else if (HIER && d.kind == MPE_HIER_MOVING) {
+          // L1F4_MovingTarget.py:157-212.  Every adversary gets the same sum: 10 per (good agent, anybody)
+          // contact, +50 after each good agent once the running count has reached 4.  Integers: exact.
+          auto hit = [&](int a, int b) {
+            return touching<T>(sPos[(2 * a) * TILE + lane] - sPos[(2 * b) * TILE + lane],
+                               sPos[(2 * a + 1) * TILE + lane] - sPos[(2 * b + 1) * TILE + lane], d.size[a] + d.size[b]);
+          };
+          int count = 0, bonus = 0, caught = 0;  // caught: (good, adversary) contacts
+          for (int gi = 0; gi < d.n_good; ++gi) {
+            const int g = d.good_list[gi];
+            for (int o = 0; o < A; ++o) {
+              if (o == g) continue;
+              const int h = hit(g, o) ? 1 : 0;
+              count += h;
+              caught += bit(d.adversary, o) ? h : 0;
+            }
+            bonus += count >= 4 ? 1 : 0;
+          }
+          for (int i = chunk; i < A; i += NCH) {
+            const bool i_adv = bit(d.adversary, i);
+            int c_i = 0;  // benchmark_data (:128-140): touching agents of the other team
+            for (int a = 0; a < A; ++a)
+              if (bit(d.adversary, a) != i_adv) c_i += hit(a, i) ? 1 : 0;
+            T r_i = i_adv ? T(10 * count + 50 * bonus) : (bit(d.collide, i) ? -T(c_i) : T(0));
+            r_i = r_i - tag_bound<T>(t_abs<T>(sPos[(2 * i) * TILE + lane]));
+            r_i = r_i - tag_bound<T>(t_abs<T>(sPos[(2 * i + 1) * TILE + lane]));
+            if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
+            if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, T(c_i));
+            if (want_stats) {
+              const double s_r = group_sum(active ? (double)r_i : 0.0, TILE);
+              const double s_c = group_sum(active ? (double)c_i : 0.0, TILE);
+              if (lane == 0) { srow[i] += s_r; srow[A + i] += s_c; }
+            }
+          }
+          if (want_stats && chunk == 0) {
+            const double s_t = group_sum(active ? (double)caught : 0.0, TILE);
+            const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
+            if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
         } else if (HIER && d.kind == MPE_HIER_PURSUIT) {
           // n_o = number of targets agent o touches (is_collision, L1F2_3Targets_100observe.py:150-154)

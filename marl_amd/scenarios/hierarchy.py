@@ -13,7 +13,9 @@ landmarks.  ``scenarios.load('<reference file name>')`` resolves to ``Scenario``
   * ``benchmark_data`` returns the number of touching agents of the other team as a ``[B]`` tensor
     (L1F2_3Targets_100observe.py:136-148).
 
-Not covered: the *_MovingTarget files (scripted prey, different observation text).
+The two *_MovingTarget files (L1F4_MovingTarget.py, S1L2F4_MovingTarget.py) are presets too: no
+landmarks, one good agent (the prey, last) that every adversary chases; their own observation and
+reward text runs as kind MPE_HIER_MOVING (reward_variant 0 / 1 = which of the two files' text).
 """
 from marl_amd import _hip
 from marl_amd.core import World, Agent, Landmark
@@ -21,11 +23,11 @@ from marl_amd.scenario import HipScenario
 
 
 def _preset(n_super, n_leader, n_follower, n_landmarks, zoom, leader_obs, scale_sizes, follower_forced,
-            leader_force, leader_forced, super_force=-1, reward_variant=0):
+            leader_force, leader_forced, super_force=-1, reward_variant=0, n_good=0, dim_c=7, moving=False):
     return dict(n_super=n_super, n_leader=n_leader, n_follower=n_follower, n_landmarks=n_landmarks, zoom=zoom,
                 leader_obs=leader_obs, scale_sizes=scale_sizes, follower_forced=follower_forced,
                 leader_force=leader_force, leader_forced=leader_forced, super_force=super_force,
-                reward_variant=reward_variant)
+                reward_variant=reward_variant, n_good=n_good, dim_c=dim_c, moving=moving)
 
 
 def _l1(n_follower, n_landmarks, zoom, leader_obs, scale):
@@ -57,6 +59,12 @@ PRESETS = {
     'S1L2F2_3Targets_095observe': _s1l2f2(3, 0.95, False),
     'S1L2F2_3Targets_100observe': _s1l2f2(3, 1, False),
     'S1L2F2_3Targets_105observe': _s1l2f2(3, 1.05, False),
+    # L1F4_MovingTarget.py:16-79: 3 commands, four followers obey the one leader, one prey
+    'L1F4_MovingTarget': _preset(0, 1, 4, 0, 1, 0.4, False, [1] * 4, [1], [-1], n_good=1, dim_c=3, moving=True),
+    # S1L2F4_MovingTarget.py:16-81: followers 0,1 <- leader with force_id 2, followers 2,3 <- force_id 1,
+    # both leaders <- super-leader (forced_id 0 / force_id 0)
+    'S1L2F4_MovingTarget': _preset(1, 2, 4, 0, 1, 0.4, False, [2, 2, 1, 1], [2, 1], [0, 0], 0, reward_variant=1,
+                                   n_good=1, dim_c=7, moving=True),
 }
 
 
@@ -79,16 +87,24 @@ class Scenario(HipScenario):
     def make_world(self):
         p = self.params
         world = World()
-        world.dim_c = 7                            # number of commands (:15)
+        world.dim_c = p['dim_c']                   # number of commands (:15)
         world.target_sens = 0.0
         nF, nL, nS = p['n_follower'], p['n_leader'], p['n_super']
-        self.num_good, self.num_adv, self.num_landmarks = 0, nF + nL + nS, p['n_landmarks']
+        self.num_good, self.num_adv, self.num_landmarks = p['n_good'], nF + nL + nS, p['n_landmarks']
         zoom = p['zoom']
-        world.agents = [Agent() for _ in range(self.num_adv)]
+        world.agents = [Agent() for _ in range(self.num_adv + self.num_good)]
         for i, agent in enumerate(world.agents):
             agent.name = 'agent %d' % i
             agent.collide = True
             agent.adversary, agent.good = True, False
+            if i >= self.num_adv:                  # prey (L1F4_MovingTarget.py:69-84)
+                agent.adversary, agent.good = False, True
+                agent.silent = True
+                agent.advfollower, agent.advleader, agent.advsuperleader = False, False, False
+                agent.obs_r = 10
+                agent.force_id, agent.forced_id = -1, -1
+                agent.size, agent.accel, agent.max_speed = 0.05, 4.0, 1.3
+                continue
             if i < nF:                             # followers (:36-46)
                 agent.silent = True
                 agent.advfollower, agent.advleader, agent.advsuperleader = True, False, False
@@ -116,11 +132,11 @@ class Scenario(HipScenario):
             landmark.boundary = False
             landmark.adversary, landmark.good, landmark.silent = False, True, True
             landmark.advfollower = landmark.advleader = landmark.advsuperleader = False
-        world.hip_kind = _hip.MPE_HIER_PURSUIT
+        world.hip_kind = _hip.MPE_HIER_MOVING if p['moving'] else _hip.MPE_HIER_PURSUIT
         world.reward_variant = p['reward_variant']
         world.n_target_obs = 3                     # target_pos[0:3] (:251-253)
         world.agent_pos_range = 1.0                # :127
-        world.landmark_pos_range = 1.0             # :132
+        world.landmark_pos_range = 0.9 if p['moving'] else 1.0   # :132 (L1F4_MovingTarget.py:124)
         return self._finish_world(world)
 
     def good_agents(self, world):

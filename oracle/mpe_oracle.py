@@ -219,13 +219,15 @@ def hier_spec_from_golden(g):
     from the reference's make_world() (tests/golden/gen_golden.py:rollout_hier)."""
     A = int(g['spec_n_agents'])
     E = len(g['spec_size'])
+    moving = 'spec_moving_target' in g.files and bool(g['spec_moving_target'])
     return ScenarioSpec(
-        kind=HIER_MOVING if ('spec_moving_target' in g.files and bool(g['spec_moving_target'])) else HIER_PURSUIT,
+        kind=HIER_MOVING if moving else HIER_PURSUIT,
         n_agents=A, n_landmarks=E - A, adversary=[bool(x) for x in g['spec_adversary']],
         size=[float(x) for x in g['spec_size']], accel=[float(x) for x in g['spec_accel']],
         max_speed=[float(x) for x in g['spec_max_speed']], collide=[bool(x) for x in g['spec_collide']],
         movable=[bool(x) for x in g['spec_movable']], u_noise=[None] * A, mass=[1.0] * E,
-        agent_pos_range=1.0, landmark_pos_range=1.0, dim_c=int(g['spec_dim_c']),
+        agent_pos_range=1.0, landmark_pos_range=0.9 if moving else 1.0,   # L1F4_MovingTarget.py:124
+        dim_c=int(g['spec_dim_c']),
         silent=[bool(x) for x in g['spec_silent']], force_id=[int(x) for x in g['spec_force_id']],
         forced_id=[int(x) for x in g['spec_forced_id']], advleader=[bool(x) for x in g['spec_advleader']],
         advsuperleader=[bool(x) for x in g['spec_advsuperleader']], obs_r=[float(x) for x in g['spec_obs_r']],

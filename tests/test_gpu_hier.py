@@ -25,7 +25,14 @@ F64_TOL = 1e-9
 BASES = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
          'L1F1_10Targets_wide', 'L1F4_3Targets_wide', 'S1L2F2_10Targets_wide',
          'S1L2F2_10Targets_wide_rewardFixed']
-HIER_CASES = ['h_' + b + suf for b in BASES for suf in ('', '_dense')]
+# the two *_MovingTarget files (kind MPE_HIER_MOVING): a moving prey instead of landmarks
+MOVING = ['L1F4_MovingTarget', 'S1L2F4_MovingTarget']
+HIER_CASES = (['h_' + b + suf for b in BASES for suf in ('', '_dense')]
+              + ['m_' + b + suf for b in MOVING for suf in ('', '_dense', '_crowd')])
+
+
+def _spec_of(golden_dir, base):
+    return O.hier_spec_from_golden(_load(golden_dir, ('m_' if base in MOVING else 'h_') + base))
 
 
 def _load(golden_dir, name):
@@ -139,6 +146,7 @@ def _rand_rollout(spec, B, dtype, steps, seed, reward_variant=None):
     E, A = spec.n_entities, spec.n_agents
     pos = rng.uniform(-1.1, 1.1, (E, 2, B))
     pos[:, :, : B // 2] *= 0.25                                          # dense half: contacts, visible targets
+    pos[:, :, : B // 16] *= 0.1                                          # a crowd: the count >= 4 bonus of MovingTarget
     vel = rng.uniform(-0.5, 0.5, (A, 2, B))
     lf0 = rng.uniform(-1, 1, (A, 2, B))
     acts = rng.rand(steps, sum(spec.act_dims), B)
@@ -146,11 +154,11 @@ def _rand_rollout(spec, B, dtype, steps, seed, reward_variant=None):
 
 
 @pytest.mark.parametrize('variant', [0, 1])
-@pytest.mark.parametrize('which', ['custom', 'S1L2F2_10Targets_wide', 'L1F4_3Targets_wide'])
+@pytest.mark.parametrize('which', ['custom', 'S1L2F2_10Targets_wide', 'L1F4_3Targets_wide'] + MOVING)
 def test_f64_random_batch_matches_oracle(golden_dir, which, variant, force_tile):
     """20 011 envs (ragged last tile) against the batched CPU oracle: every branch of the command
     decode and of both reward texts."""
-    base = _custom_spec() if which == 'custom' else O.hier_spec_from_golden(_load(golden_dir, 'h_' + which))
+    base = _custom_spec() if which == 'custom' else _spec_of(golden_dir, which)
     B, steps = 20011, 4
     spec, pos, vel, lf0, acts = _rand_rollout(base, B, torch.float64, steps, 7, variant)
     sim = HipSim(spec, B, torch.float64)
@@ -200,11 +208,11 @@ def test_split_entry_points_equal_fused(golden_dir, dtype, force_tile):
     assert (a.pos[..., B:] == 0).all() and (a.vel[..., B:] == 0).all() and (a.lforce[..., B:] == 0).all()
 
 
-@pytest.mark.parametrize('base', BASES)
+@pytest.mark.parametrize('base', BASES + MOVING)
 def test_register_and_tile_kernels_bit_identical(golden_dir, base):
     """Both kernels implement the same operation order: every output equal bit for bit, f64 and f32,
     on states that exercise contacts, visibility and all seven commands."""
-    spec = O.hier_spec_from_golden(_load(golden_dir, 'h_' + base))
+    spec = _spec_of(golden_dir, base)
     B = 4096 + 11
     for dtype in (torch.float64, torch.float32):
         _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 4, 21)
@@ -224,8 +232,9 @@ def test_register_and_tile_kernels_bit_identical(golden_dir, base):
             assert np.array_equal(x, y, equal_nan=True)
 
 
-def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, force_tile):
-    spec = O.hier_spec_from_golden(_load(golden_dir, 'h_S1L2F2_10Targets_wide'))
+@pytest.mark.parametrize('base', ['S1L2F2_10Targets_wide', 'S1L2F4_MovingTarget'])
+def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, base, force_tile):
+    spec = _spec_of(golden_dir, base)
     B, steps = 5000 + 3, 3
     _, pos, vel, lf0, acts = _rand_rollout(spec, B, torch.float64, steps, 11)
     from marl_amd import _hip
@@ -247,6 +256,8 @@ def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, force_tile):
     got = out.cpu().numpy()
     np.testing.assert_allclose(got[:2 * A], want[:2 * A], rtol=1e-9, atol=1e-6)
     assert got[2 * A + 1] == want[2 * A + 1] and got[2 * A] >= 0
+    if base in MOVING:                                                   # [2A]: (prey, adversary) contacts
+        assert got[2 * A] == want[2 * A - 1] > 0
     assert _hip.lib.mpe_info_width(sim.desc) == 1
 
 

@@ -75,7 +75,7 @@ def test_descriptor_validation_and_error_codes():
     assert lib.mpe_desc_check(bad) == -2
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.n_landmarks = 125
     assert lib.mpe_desc_check(bad) == -2
-    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.kind = 10
+    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.kind = 11
     assert lib.mpe_desc_check(bad) == -5
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.movable[4] = 1
     assert lib.mpe_desc_check(bad) == -5
@@ -150,7 +150,7 @@ def test_spaces_and_scenario_loader():
 
 GOLDEN_HIER = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
                'L1F1_10Targets_wide', 'L1F4_3Targets_wide', 'S1L2F2_10Targets_wide',
-               'S1L2F2_10Targets_wide_rewardFixed']
+               'S1L2F2_10Targets_wide_rewardFixed', 'L1F4_MovingTarget', 'S1L2F4_MovingTarget']
 
 
 @pytest.mark.parametrize('name', GOLDEN_HIER)
@@ -159,7 +159,8 @@ def test_hierarchy_presets_match_the_reference_worlds(name):
     with the parameters the golden generator read back from the reference's make_world()."""
     import marl_amd.scenarios as scenarios
     from marl_amd import _hip
-    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'h_%s.npz' % name))
+    moving = name.endswith('MovingTarget')
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', '%s_%s.npz' % ('m' if moving else 'h', name)))
     spec = O.hier_spec_from_golden(g)
     sc = scenarios.load(name + '.py').Scenario(observation_radius=1.0)
     sc._finish_world = lambda world: world              # no GPU here: skip allocation
@@ -168,7 +169,9 @@ def test_hierarchy_presets_match_the_reference_worlds(name):
     want = _desc(spec)
     assert bytes(d) == bytes(want)
     assert [a.silent for a in world.agents] == spec.silent
-    assert d.kind == _hip.MPE_HIER_PURSUIT and d.dim_c == 7
+    assert d.kind == (_hip.MPE_HIER_MOVING if moving else _hip.MPE_HIER_PURSUIT)
+    assert d.dim_c == (3 if name == 'L1F4_MovingTarget' else 7)
+    assert [lib_dim for lib_dim in (_hip.lib.mpe_obs_dim(d, i) for i in range(spec.n_agents))] == spec.obs_dims
 
 
 def test_hierarchy_presets_cover_every_reference_file():
@@ -176,12 +179,16 @@ def test_hierarchy_presets_cover_every_reference_file():
     ref = ['L1F1_10Targets_wide', 'L1F2_10Targets_wide', 'L1F4_3Targets_wide', 'S1L1F1_10Targets_wide',
            'S1L2F2_10Targets_wide', 'S1L2F2_10Targets_wide_rewardFixed']
     ref += ['%s_3Targets_%sobserve' % (f, z) for f in ('L1F2', 'S1L2F2') for z in ('075', '090', '095', '100', '105')]
+    ref += ['L1F4_MovingTarget', 'S1L2F4_MovingTarget']
+    import glob
+    live = sorted(os.path.basename(f)[:-3] for f in glob.glob('/root/reference/multiagent-particle-envs/multiagent/scenarios/[LS]*.py'))
+    assert not live or live == sorted(ref)                  # the reference tree exists in the build container only
     assert sorted(hierarchy.PRESETS) == sorted(ref)
     for name in ref:
         sc = hierarchy.bound_module(name).Scenario()
         sc._finish_world = lambda world: world
         w = sc.make_world()
-        assert w.descriptor().n_agents == sum(hierarchy.PRESETS[name][k] for k in ('n_super', 'n_leader', 'n_follower'))
+        assert w.descriptor().n_agents == sum(hierarchy.PRESETS[name][k] for k in ('n_super', 'n_leader', 'n_follower', 'n_good'))
     with pytest.raises(TypeError):
         hierarchy.Scenario(bogus=1)
 
