@@ -25,36 +25,25 @@ namespace mpe {
 constexpr int kHierDimC = 7;
 constexpr int kHierTargets = 3;
 
-template <typename T, int A, int L, int NF, int THREADS, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KParams<T> p) {
-  constexpr int E = A + L;
-  constexpr int C = kHierDimC;
-  constexpr int NT = L < kHierTargets ? L : kHierTargets;
-  static_assert(NF >= 0 && NF < A && A <= 6, "followers first, at least one leader; counter packing holds 6 agents");
+// World.step for one env per lane (shared by hier_kernel and moving_kernel): action decode, leader force,
+// pair forces, integration, comm / leader_force write-back; or, when only observing, the leader_force load.
+// Agent order: NF silent followers, then the speaking leaders, then NG silent good agents (the prey of the
+// *_MovingTarget files; 0 in the Targets files).
+template <typename T, int A, int E, int NF, int NG, int C, bool DO_STEP, bool DO_OBS>
+__device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk0, const uint32_t lo, T (&px)[E], T (&py)[E],
+                                          T (&vx)[A], T (&vy)[A], T (&lfx)[A], T (&lfy)[A]) {
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
-  const bool active = blk0 + threadIdx.x < p.B;
-  const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
-  // first action row of agent a (compile-time: followers first)
-  auto arow = [](int a) { return a < NF ? 5 * a : 5 * NF + (5 + C) * (a - NF); };
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
-  T px[E], py[E], vx[A], vy[A], lfx[A], lfy[A];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    px[e] = wpos.ld_state(2 * e, lo);
-    py[e] = wpos.ld_state(2 * e + 1, lo);
-  }
-#pragma unroll
-  for (int a = 0; a < A; ++a) {
-    vx[a] = wvel.ld_state(2 * a, lo);
-    vy[a] = wvel.ld_state(2 * a + 1, lo);
-    lfx[a] = lfy[a] = T(0);
-  }
-
+  constexpr int LE = A - NG;  // leaders are agents NF..LE-1
+  static_assert(NF >= 0 && NF < LE && NG >= 0, "followers, at least one leader, good agents");
+  // first action row of agent a (compile-time)
+  auto arow = [](int a) {
+    return a < NF ? 5 * a : (a < LE ? 5 * NF + (5 + C) * (a - NF) : 5 * NF + (5 + C) * (LE - NF) + 5 * (a - LE));
+  };
   if (DO_STEP) {
     const Win<T> wact(p.act + blk0, ld);
-    T a1[A], a2[A], a3[A], a4[A], c[A - NF > 0 ? A - NF : 1][C];
+    T a1[A], a2[A], a3[A], a4[A], c[LE - NF][C];
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // a[0] (the no-op slot) is never read (environment.py:189-190)
       a1[a] = wact.ld_stream(arow(a) + 1, lo);
@@ -63,7 +52,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       a4[a] = wact.ld_stream(arow(a) + 4, lo);
     }
 #pragma unroll
-    for (int l = NF; l < A; ++l)
+    for (int l = NF; l < LE; ++l)
 #pragma unroll
       for (int k = 0; k < C; ++k) c[l - NF][k] = wact.ld_stream(arow(l) + 5 + k, lo);
 
@@ -74,9 +63,9 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       Fy[a] = (a3[a] - a4[a]) * d.accel[a];
     }
     // core.py:153-194 (same order as mpe_device.h:leader_force): leaders in agent order
-    int cmd[A - NF > 0 ? A - NF : 1];
+    int cmd[LE - NF];
 #pragma unroll
-    for (int l = NF; l < A; ++l) {  // np.argmax: first maximum, a NaN wins
+    for (int l = NF; l < LE; ++l) {  // np.argmax: first maximum, a NaN wins
       int k_best = 0;
       T best = c[l - NF][0];
 #pragma unroll
@@ -86,14 +75,15 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         best = take ? v : best;
         k_best = take ? k : k_best;
       }
-      cmd[l - NF] = k_best;
+      // three commands only: nothing / towards / away (core.py:169-171)
+      cmd[l - NF] = C == 3 ? (k_best == 0 ? 0 : (k_best == 1 ? 5 : 6)) : k_best;
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       const int want = d.forced_id[a];
       if (want < 0) continue;
 #pragma unroll
-      for (int l = NF; l < A; ++l) {  // silent agents command nobody: their c is zero (argmax 0)
+      for (int l = NF; l < LE; ++l) {  // silent agents command nobody: their c is zero (argmax 0)
         if (d.force_id[l] != want) continue;
         if (bit(d.advsuper, l)) {  // observed only (core.py:162-163)
           lfx[a] = c[l - NF][0];
@@ -121,7 +111,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int k = 0; k < C; ++k)
-          wcomm.st_state(a * C + k, lo, a < NF ? T(0) : c[a < NF ? 0 : a - NF][k]);
+          wcomm.st_state(a * C + k, lo, (a < NF || a >= LE) ? T(0) : c[(a < NF || a >= LE) ? 0 : a - NF][k]);
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:199-205, b ascending; only a is pushed
@@ -163,6 +153,35 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       lfy[a] = wlf0.ld_state(2 * a + 1, lo);
     }
   }
+
+}
+
+template <typename T, int A, int L, int NF, int THREADS, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KParams<T> p) {
+  constexpr int E = A + L;
+  constexpr int C = kHierDimC;
+  constexpr int NT = L < kHierTargets ? L : kHierTargets;
+  static_assert(A <= 6, "counter packing holds 6 agents");
+  const DevDesc<T> &d = p.d;
+  const int64_t ld = p.ld;
+  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
+  const bool active = blk0 + threadIdx.x < p.B;
+  const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
+  const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
+  T px[E], py[E], vx[A], vy[A], lfx[A], lfy[A];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    px[e] = wpos.ld_state(2 * e, lo);
+    py[e] = wpos.ld_state(2 * e + 1, lo);
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    vx[a] = wvel.ld_state(2 * a, lo);
+    vy[a] = wvel.ld_state(2 * a + 1, lo);
+    lfx[a] = lfy[a] = T(0);
+  }
+
+  hier_step<T, A, E, NF, 0, C, DO_STEP, DO_OBS>(p, blk0, lo, px, py, vx, vy, lfx, lfy);
 
   if (DO_OBS) {
     const bool want_obs = p.obs != nullptr, want_rew = p.rew != nullptr, want_info = p.info != nullptr,
@@ -301,6 +320,133 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
             sred[wave][A + i] = (double)(((i < 3 ? pk0 : pk1) >> (10 * (i < 3 ? i : i - 3))) & 0x3FFu);
           }
           sred[wave][2 * A] = (double)fh;
+          sred[wave][2 * A + 1] = n_active;
+        }
+        __syncthreads();
+        if (threadIdx.x < W) {
+          double s = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += sred[w][threadIdx.x];
+          p.stats[(int64_t)blockIdx.x * W + threadIdx.x] += s;
+        }
+      }
+    }
+  }
+}
+
+// The two *_MovingTarget files (L1F4_MovingTarget.py: A = 6, NF = 4, C = 3; S1L2F4_MovingTarget.py: A = 8, NF = 4,
+// C = 7): no landmarks, the last agent is the prey.  Same step as above; own observation (distance, not
+// squared-distance, radius test; command links visible only in the L1F4 text; the prey sees everybody in
+// absolute coordinates) and reward text (10 per (prey, anybody) contact, +50 from four contacts on, the
+// same for every adversary).  Stock flags checked on the host (mpe_hip.hip:moving_variant).
+#ifndef MPE_MOVING_CAP
+#define MPE_MOVING_CAP 2  // S1L2F4_MovingTarget 1Mi f32: 388.8 us at 3, 376.0 at 2, 387.5 at 4 (477 rows per wavefront)
+#endif
+template <typename T, int A, int NF, int C, int THREADS, bool DO_STEP, bool DO_OBS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_MOVING_CAP))) void moving_kernel(const KParams<T> p) {
+  constexpr int E = A, G = A - 1;  // G: the prey
+  const DevDesc<T> &d = p.d;
+  const int64_t ld = p.ld;
+  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;
+  const bool active = blk0 + threadIdx.x < p.B;
+  const uint32_t lo = active ? threadIdx.x : kNoLane;
+  const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
+  T px[E], py[E], vx[A], vy[A], lfx[A], lfy[A];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    px[e] = wpos.ld_state(2 * e, lo);
+    py[e] = wpos.ld_state(2 * e + 1, lo);
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    vx[a] = wvel.ld_state(2 * a, lo);
+    vy[a] = wvel.ld_state(2 * a + 1, lo);
+    lfx[a] = lfy[a] = T(0);
+  }
+  hier_step<T, A, E, NF, 1, C, DO_STEP, DO_OBS>(p, blk0, lo, px, py, vx, vy, lfx, lfy);
+
+  if (DO_OBS) {
+    const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;
+    if (p.obs != nullptr) {
+#pragma unroll
+      for (int i = 0; i < A; ++i) {  // L1F4_MovingTarget.py:214-258
+        const Win<T> wobs(p.obs + blk0 + (int64_t)d.obs_row0[i] * ld, ld);
+        int r = 0;
+        wobs.st_stream(r++, lo, vx[i]);
+        wobs.st_stream(r++, lo, vy[i]);
+        wobs.st_stream(r++, lo, px[i]);
+        wobs.st_stream(r++, lo, py[i]);
+        const T rad = d.obs_r[i];
+        const int fi = d.force_id[i], fdi = d.forced_id[i];
+        bool vis[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          if (j == i) continue;
+          const T dx = px[j] - px[i], dy = py[j] - py[i];
+          const bool linked = d.reward_variant == 0 &&
+                              ((fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]));
+          vis[j] = i == G || linked || t_sqrt<T>(dx * dx + dy * dy) < rad;
+          wobs.st_stream(r++, lo, i == G ? px[j] : (vis[j] ? dx : T(0)));  // the prey: absolute (:249-251)
+          wobs.st_stream(r++, lo, i == G ? py[j] : (vis[j] ? dy : T(0)));
+        }
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          if (j == i) continue;
+          wobs.st_stream(r++, lo, vis[j] ? vx[j] : T(0));
+          wobs.st_stream(r++, lo, vis[j] ? vy[j] : T(0));
+        }
+        if (bit(d.obs_lf, i)) {
+          wobs.st_stream(r++, lo, lfx[i]);
+          wobs.st_stream(r++, lo, lfy[i]);
+        }
+      }
+    }
+    if (want_rew || want_info || want_stats) {
+      int coll[A];  // benchmark_data (:128-140): adversary <-> prey contacts
+      int count = 0;
+#pragma unroll
+      for (int o = 0; o < G; ++o) {
+        coll[o] = touching<T>(px[G] - px[o], py[G] - py[o], d.size[G] + d.size[o]) ? 1 : 0;
+        count += coll[o];
+      }
+      coll[G] = count;
+      const T adv_r = T(10 * count + (count >= 4 ? 50 : 0));  // :186-199 (integers: exact)
+      T rew[A];
+      const Win<T> wrew(p.rew + blk0, ld), winfo(p.info + blk0, ld);
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+        T r_i = i == G ? T(0) - T(count) : adv_r;  // :162-171
+        r_i = r_i - tag_bound_sel<T>(t_abs<T>(px[i]));
+        r_i = r_i - tag_bound_sel<T>(t_abs<T>(py[i]));
+        rew[i] = r_i;
+        if (want_rew) wrew.st_stream(i, lo, r_i);
+        if (want_info) winfo.st_stream(i, lo, T(coll[i]));
+      }
+      if (want_stats) {
+        constexpr int W = 2 * A + 2;
+        constexpr int NW = THREADS / 64;
+        __shared__ double sred[NW][W];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // A - 1 one-bit contact flags (<= 64 per wavefront: 7 bits) + their sum (<= 7 per lane: 9 bits)
+        uint64_t pk = 0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) pk |= (uint64_t)coll[i] << (7 * i);
+        uint32_t pk_lo = (uint32_t)(pk & 0xFFFFFFFu), pk_hi = (uint32_t)(pk >> 28);
+        pk_lo = wave_sum_u32(active ? pk_lo : 0u);
+        pk_hi = wave_sum_u32(active ? pk_hi : 0u);
+        const uint32_t caught = wave_sum_u32(active ? (uint32_t)count : 0u);
+        const double n_active = (double)__builtin_popcountll(__ballot(active));
+        double rsum[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) rsum[i] = group_sum(active ? (double)rew[i] : 0.0, 64);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < A; ++i) {
+            sred[wave][i] = rsum[i];
+            sred[wave][A + i] = i == G ? (double)caught
+                                       : (double)(((i < 4 ? pk_lo : pk_hi) >> (7 * (i < 4 ? i : i - 4))) & 0x7Fu);
+          }
+          sred[wave][2 * A] = (double)caught;
           sred[wave][2 * A + 1] = n_active;
         }
         __syncthreads();

@@ -329,8 +329,28 @@ enum SmallId {
   COMM_SPEAKER_LISTENER,
   COMM_REFERENCE,
   COMM_CRYPTO,
-  WCOMM_4_2_1_2_2  // simple_world_comm (mpe_wcomm_kernel.h)
+  WCOMM_4_2_1_2_2,  // simple_world_comm (mpe_wcomm_kernel.h)
+  MOVING_6_4_3,     // L1F4_MovingTarget (agents, followers, dim_c; mpe_hier_kernel.h:moving_kernel)
+  MOVING_8_4_7      // S1L2F4_MovingTarget
 };
+
+// Stock shape of a *_MovingTarget world (moving_kernel header), or SMALL_NONE.
+static SmallId moving_variant(const mpe_scenario_desc *h) {
+  const int A = h->n_agents;
+  if (h->n_landmarks != 0) return SMALL_NONE;
+  SmallId id;
+  if (A == 6 && h->dim_c == 3) id = MOVING_6_4_3;
+  else if (A == 8 && h->dim_c == 7) id = MOVING_8_4_7;
+  else return SMALL_NONE;
+  const int nf = 4;
+  for (int a = 0; a < A; ++a) {
+    if ((h->silent[a] != 0) != (a < nf || a == A - 1)) return SMALL_NONE;   // followers, leaders, prey
+    if ((h->adversary[a] != 0) != (a < A - 1)) return SMALL_NONE;
+    if (h->silent[a] && h->force_id[a] >= 0) return SMALL_NONE;             // a silent agent commands nobody
+    if (!h->movable[a] || !h->collide[a] || !(h->max_speed[a] >= 0.0) || h->u_noise[a] != 0.0) return SMALL_NONE;
+  }
+  return id;
+}
 
 // Stock shape of simple_world_comm (mpe_wcomm_kernel.h header), or SMALL_NONE.
 static SmallId wcomm_variant(const mpe_scenario_desc *h) {
@@ -397,6 +417,7 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
     case MPE_SIMPLE_REFERENCE: return comm_variant(h);
     case MPE_SIMPLE_CRYPTO: return h->dim_c == 4 ? COMM_CRYPTO : SMALL_NONE;  // roles, shape: mpe_desc_check
     case MPE_WORLD_COMM: return wcomm_variant(h);
+    case MPE_HIER_MOVING: return moving_variant(h);
     default: return SMALL_NONE;
   }
   for (int a = 0; a < A; ++a) {
@@ -478,6 +499,15 @@ static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStrea
       case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
       case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
       case COMM_REFERENCE: return launch_comm<T, MPE_SIMPLE_REFERENCE, 10, DO_STEP, DO_OBS>(p, s);
+      case MOVING_6_4_3:
+      case MOVING_8_4_7: {
+        const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+        if (sv == MOVING_6_4_3)
+          hipLaunchKernelGGL((moving_kernel<T, 6, 4, 3, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+        else
+          hipLaunchKernelGGL((moving_kernel<T, 8, 4, 7, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
       case WCOMM_4_2_1_2_2: {
         const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
         hipLaunchKernelGGL((wcomm_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);

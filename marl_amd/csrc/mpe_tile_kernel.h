@@ -654,7 +654,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             int c_i = 0;  // benchmark_data (:128-140): touching agents of the other team
             for (int a = 0; a < A; ++a)
               if (bit(d.adversary, a) != i_adv) c_i += hit(a, i) ? 1 : 0;
-            T r_i = i_adv ? T(10 * count + 50 * bonus) : (bit(d.collide, i) ? -T(c_i) : T(0));
+            T r_i = i_adv ? T(10 * count + 50 * bonus) : (bit(d.collide, i) ? T(0) - T(c_i) : T(0));
             r_i = r_i - tag_bound<T>(t_abs<T>(sPos[(2 * i) * TILE + lane]));
             r_i = r_i - tag_bound<T>(t_abs<T>(sPos[(2 * i + 1) * TILE + lane]));
             if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
