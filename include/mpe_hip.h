@@ -259,6 +259,22 @@ int mpe_target_move_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, ui
                         void *stream);
 
 /*
+ * Scripted prey of the fork's training loop (experiments/simple_train.py:157-205; the loop overwrites
+ * action_n[-1] with it, :262-273): the 5 physical action entries of agent `agent` for every env.
+ *   mode 0  good_agent_action: head for the corner of [-0.9, 0.9]^2 whose summed distance to all other
+ *           agents is largest (first maximum; np.linalg.norm per agent, summed in agent order), gain 1
+ *   mode 1  good_agent_victim_action: head for agent `target`, gain 7
+ * act = min(|offset| / 2 * gain, cap) in the slot of the offset's sign (simple_train.py:175-187), cap =
+ * 1.3 in the reference.  Reads pos; writes act_out [5][ld] (e.g. the agent's rows of the action buffer:
+ * act + mpe_act_row0(desc, agent) * ld) and, when not NULL, point_out [2][ld] (the corner / target
+ * position: the function's second return value).
+ */
+int mpe_scripted_action_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int agent, int mode, int target,
+                            double cap, const void *pos, void *act_out, void *point_out, void *stream);
+int mpe_scripted_action_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int agent, int mode, int target,
+                            double cap, const void *pos, void *act_out, void *point_out, void *stream);
+
+/*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,
  * experiments/simple_train.py:284-286, and info_n per agent, :357).  Width = 2*A + 2 doubles:
  * [0,A) sum of reward per agent, [A,2A) sum of collisions per agent (info column 0 for

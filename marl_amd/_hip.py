@@ -111,6 +111,8 @@ def _load():
         f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, vp, bp, vp]
         f = getattr(L, 'mpe_target_move_' + suf)      # desc, B, ld, seed, counter, env_id0, buffers, count, stream
         f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, bp, vp, vp]
+        f = getattr(L, 'mpe_scripted_action_' + suf)  # desc, B, ld, agent, mode, target, cap, pos, act, point, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, ci, ci, ci, C.c_double, vp, vp, vp, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci]
     L.mpe_stats_reduce.restype = ci

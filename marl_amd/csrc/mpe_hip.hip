@@ -733,6 +733,67 @@ static int target_move_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, u
   return (int)hipGetLastError();
 }
 
+// good_agent_action / good_agent_victim_action (experiments/simple_train.py:157-205): one env per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void scripted_action_kernel(int64_t B, int64_t ld, int A, int agent, int mode,
+                                                               int target, T cap, const T *pos, T *act, T *point) {
+  const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (env >= B) return;
+  const T px = pos[(int64_t)(2 * agent) * ld + env], py = pos[(int64_t)(2 * agent + 1) * ld + env];
+  T tx, ty, gain;
+  if (mode == 0) {  // :158-168: first corner with the largest summed distance to the other agents
+    const T ex[4] = {T(-0.9), T(0.9), T(-0.9), T(0.9)}, ey[4] = {T(0.9), T(0.9), T(-0.9), T(-0.9)};
+    T best = T(0);
+    tx = ex[0];
+    ty = ey[0];
+    for (int i = 0; i < 4; ++i) {
+      T dsum = T(0);
+      for (int o = 0; o < A; ++o) {
+        if (o == agent) continue;
+        dsum = dsum + t_norm2<T>(ex[i] - pos[(int64_t)(2 * o) * ld + env], ey[i] - pos[(int64_t)(2 * o + 1) * ld + env]);
+      }
+      const bool take = i == 0 || dsum > best;
+      best = take ? dsum : best;
+      tx = take ? ex[i] : tx;
+      ty = take ? ey[i] : ty;
+    }
+    gain = T(1);
+  } else {  // :191
+    tx = pos[(int64_t)(2 * target) * ld + env];
+    ty = pos[(int64_t)(2 * target + 1) * ld + env];
+    gain = T(7);
+  }
+  const T vx = (tx - px) / T(2), vy = (ty - py) / T(2);
+  T mx = t_abs<T>(vx) * gain, my = t_abs<T>(vy) * gain;
+  mx = cap < mx ? cap : mx;  // Python min(m, cap)
+  my = cap < my ? cap : my;
+  act[env] = T(0);
+  act[ld + env] = vx < T(0) ? T(0) : mx;
+  act[2 * ld + env] = vx < T(0) ? mx : T(0);
+  act[3 * ld + env] = vy < T(0) ? T(0) : my;
+  act[4 * ld + env] = vy < T(0) ? my : T(0);
+  if (point != nullptr) {
+    point[env] = tx;
+    point[ld + env] = ty;
+  }
+}
+
+template <typename T>
+static int scripted_action_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, int agent, int mode, int target,
+                                double cap, const void *pos, void *act, void *point, void *stream) {
+  int rc = check_common<T>(h, B, ld);
+  if (rc) return rc;
+  if (!pos || !act) return MPE_ERR_NULL;
+  if (agent < 0 || agent >= h->n_agents || (mode != 0 && mode != 1) || std::isnan(cap)) return MPE_ERR_ARG;
+  if (mode == 1 && (target < 0 || target >= h->n_agents)) return MPE_ERR_ARG;
+  if (!h->movable[agent]) return MPE_ERR_UNSUPPORTED;  // no physical action entries to write
+  if (misaligned<T>(pos) || misaligned<T>(act) || misaligned<T>(point)) return MPE_ERR_ALIGN;
+  const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+  hipLaunchKernelGGL(scripted_action_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld, h->n_agents, agent, mode,
+                     target, (T)cap, (const T *)pos, (T *)act, (T *)point);
+  return (int)hipGetLastError();
+}
+
 // One workgroup per column; rows are summed in a fixed order (thread t takes rows t, t+256, ...
 // sequentially, then a wavefront butterfly, then the 4 wavefront partials in a fixed order), so the
 // result is bitwise reproducible for a given (rows, width).
@@ -777,6 +838,11 @@ extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, do
                                        uint32_t counter, uint64_t env_id0, const mpe_buffers *b,               \
                                        int32_t *count, void *stream) {                                         \
     return target_move_impl<T>(d, B, ld, seed, counter, env_id0, b, count, stream);                            \
+  }                                                                                                            \
+  extern "C" int mpe_scripted_action_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, int agent,       \
+                                           int mode, int target, double cap, const void *pos, void *act_out,   \
+                                           void *point_out, void *stream) {                                    \
+    return scripted_action_impl<T>(d, B, ld, agent, mode, target, cap, pos, act_out, point_out, stream);       \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
                                  uint32_t episode, uint64_t env_id0, const uint8_t *mask,                      \

@@ -1444,6 +1444,89 @@ def target_move(spec: ScenarioSpec, pos, seed: int, counter: int, env_ids, dtype
 
 
 # --------------------------------------------------------------------------------------
+# Scripted prey (experiments/simple_train.py:157-205)             *** parity unpinned ***
+# good_agent_action / good_agent_victim_action live in the training script, which holds no fixture for
+# them and whose code is not run here (same refusal as target_move).  The serial
+# form follows the reference text statement by statement; the vectorised form is checked against it.
+# --------------------------------------------------------------------------------------
+WORLD_EDGE = [[-0.9, 0.9], [0.9, 0.9], [-0.9, -0.9], [0.9, -0.9]]      # simple_train.py:158
+
+
+def _prey_act(vec, mag, cap):
+    """simple_train.py:175-187 / :192-202: half the offset, one of the two opposing slots per axis."""
+    vec = [vec[0] / 2, vec[1] / 2]
+    act = np.array([0.0 for _ in range(5)])
+    if vec[0] < 0:
+        act[2] = min(abs(vec[0]) * mag, cap)
+    else:
+        act[1] = min(vec[0] * mag, cap)
+    if vec[1] < 0:
+        act[4] = min(abs(vec[1]) * mag, cap)
+    else:
+        act[3] = min(vec[1] * mag, cap)
+    return act
+
+
+def good_agent_action_serial(env: 'SerialEnv', agent=-1, cap=1.3):
+    """simple_train.py:157-188: head for the corner of [-0.9, 0.9]^2 whose summed distance to every other
+    agent is largest (first maximum).  Returns (act[5], target_edge[2])."""
+    me = env.agents[agent]
+    other_pos = [o.pos for o in env.agents if o is not me]
+    dis = [0.0 for _ in WORLD_EDGE]
+    for i, edge in enumerate(WORLD_EDGE):
+        for pos in other_pos:
+            dis[i] += np.linalg.norm(edge - pos)
+    idx = dis.index(max(dis))
+    target_edge = WORLD_EDGE[idx]
+    return _prey_act(target_edge - me.pos, 1, cap), np.array(target_edge)
+
+
+def good_agent_victim_action_serial(env: 'SerialEnv', target, agent=-1, cap=1.3):
+    """simple_train.py:190-205: walk towards agent `target` (the curriculum's easy prey), gain 7."""
+    me = env.agents[agent]
+    return _prey_act(env.agents[target].pos - me.pos, 7, cap)
+
+
+def scripted_action(spec: ScenarioSpec, pos, agent, mode, target=0, cap=1.3, dtype=np.float64):
+    """Vectorised form of the two functions above.  pos [E,2,B]; mode 0 = good_agent_action, 1 =
+    good_agent_victim_action(target).  Returns (act [5,B], target point [2,B])."""
+    T = np.dtype(dtype).type
+    pos = np.asarray(pos, T)
+    A = spec.n_agents
+    agent = agent % A
+    B = pos.shape[-1]
+    with np.errstate(all='ignore'):
+        if mode == 0:
+            best_d, tx, ty = None, None, None
+            for ex, ey in WORLD_EDGE:
+                d = np.zeros(B, T)
+                for o in range(A):
+                    if o == agent:
+                        continue
+                    dx, dy = T(ex) - pos[o, 0], T(ey) - pos[o, 1]
+                    d = d + (_norm2_blas(dx, dy) if T is np.float64 else np.sqrt(dx * dx + dy * dy))
+                if best_d is None:
+                    best_d, tx, ty = d, np.full(B, T(ex)), np.full(B, T(ey))
+                else:
+                    take = d > best_d
+                    best_d = np.where(take, d, best_d)
+                    tx, ty = np.where(take, T(ex), tx), np.where(take, T(ey), ty)
+            mag = T(1)
+        else:
+            tx, ty = pos[target, 0], pos[target, 1]
+            mag = T(7)
+        act = np.zeros((5, B), T)
+        for c, t in ((0, tx), (1, ty)):
+            v = (t - pos[agent, c]) / T(2)
+            neg = v < 0
+            m = np.abs(v) * mag
+            m = np.where(T(cap) < m, T(cap), m)           # Python min(m, cap)
+            act[2 + 2 * c] = np.where(neg, m, T(0))
+            act[1 + 2 * c] = np.where(neg, T(0), m)
+    return act, np.stack([tx, ty]).astype(T)
+
+
+# --------------------------------------------------------------------------------------
 # Device reset RNG restatement (this build's own spec; no reference counterpart)
 # --------------------------------------------------------------------------------------
 _M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)

@@ -1,5 +1,7 @@
 """GPU tests of the drop-in Python boundary (make_env / MultiAgentEnv.step / reset / Scenario),
 written like the loops that drive the reference (experiments/simple_train.py:257-300)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -405,3 +407,44 @@ def test_simple_crypto_episode_loop_matches_oracle():
         np.testing.assert_allclose(np.stack([_np(x) for x in rew_n]), rew, rtol=0, atol=1e-9)
         silent = ~_np(action_n[0]).any(1)
         assert (np.stack([_np(x) for x in rew_n])[0][silent] == 0).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+def test_scripted_prey_matches_oracle_and_drives_the_env(dtype):
+    """SURVEY 8f row f3 (experiments/simple_train.py:157-205, parity unpinned: see the oracle's header):
+    good_agent_action / good_agent_victim_action for every env in one launch, against the vectorised
+    oracle (f64: bit for bit, same fma norm), then used as action_n[-1] the way the training loop does."""
+    from marl_amd import make_env
+    from marl_amd.experiments import good_agent_action, good_agent_victim_action
+    B = 3000 + 7
+    env = make_env('L1F4_MovingTarget', num_envs=B, dtype=dtype, seed=3)
+    env.reset()
+    w = env.world
+    spec = O.hier_spec_from_golden(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'm_L1F4_MovingTarget.npz')))
+    w.pos[:, :, ::3] *= 2.5                                                # some envs far outside: the cap
+    w.mark_dirty()
+    prey = w.agents[-1]
+    act, edge = good_agent_action(prey, w)
+    assert tuple(act.shape) == (B, 5) and tuple(edge.shape) == (B, 2)
+    want_act, want_edge = O.scripted_action(spec, _np(w.pos), -1, 0, dtype=np.float64 if dtype == torch.float64 else np.float32)
+    if dtype == torch.float64:
+        assert np.array_equal(_np(act).T, want_act) and np.array_equal(_np(edge).T, want_edge)
+    else:
+        same = (_np(edge).T == want_edge).all(0)                           # f32 sums may pick another corner on near-ties
+        assert same.mean() > 0.999
+        np.testing.assert_allclose(_np(act).T[:, same], want_act[:, same], rtol=1e-6, atol=1e-7)
+    assert float(act.max()) == pytest.approx(1.3) and (act[:, 0] == 0).all()
+    vact = good_agent_victim_action(prey, w, w.agents[2])
+    want_v, _ = O.scripted_action(spec, _np(w.pos), -1, 1, 2, dtype=np.float64 if dtype == torch.float64 else np.float32)
+    assert np.array_equal(_np(vact).T, want_v.astype(np.float64))
+    # the loop: action_n[-1] = good_act (simple_train.py:269-273)
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    action_n = [torch.rand(B, d, generator=gen, device='cuda', dtype=dtype) for d in w.act_dims]
+    action_n[-1] = act
+    before = w.pos[-1].clone()
+    env.step(action_n)
+    moved = w.pos[-1] - before                                             # the prey accelerates towards its corner
+    pull = torch.sign(edge.t() - before)
+    far = (edge.t() - before).abs() > 0.2
+    assert ((torch.sign(moved) == pull) | ~far).float().mean() > 0.9
+

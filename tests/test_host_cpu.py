@@ -305,3 +305,23 @@ def test_simple_world_comm_geometry_and_validation():
     assert bytes(w.descriptor()) == bytes(d)
     assert [l.name for l in w.landmarks] == ['landmark 0', 'food 0', 'food 1', 'forest 0', 'forest 1']
 
+
+def test_scripted_action_argument_checks():
+    """mpe_scripted_action_* validates before it launches (safe without a GPU)."""
+    from marl_amd import _hip
+    lib = _hip.lib
+    d = _desc(O.simple_tag_spec())
+    ok = (d, 8, 8, 3, 0, 0, 1.3, 8, 8, None, None)
+    def call(**kw):
+        names = ('desc', 'B', 'ld', 'agent', 'mode', 'target', 'cap', 'pos', 'act', 'point', 'stream')
+        args = dict(zip(names, ok))
+        args.update(kw)
+        return lib.mpe_scripted_action_f64(*[args[n] for n in names])
+    assert call(pos=None) == -1 and call(act=None) == -1
+    assert call(agent=4) == -6 and call(agent=-1) == -6 and call(mode=2) == -6
+    assert call(mode=1, target=9) == -6 and call(cap=float('nan')) == -6
+    assert call(B=0) == -3 and call(ld=4) == -3
+    assert call(pos=4) == -4 and call(point=12) == -4
+    d2 = _desc(O.speaker_listener_spec())
+    assert lib.mpe_scripted_action_f64(d2, 8, 8, 0, 0, 0, 1.3, 8, 8, None, None) == -5   # the speaker cannot move
+

@@ -325,6 +325,41 @@ def test_target_move_oracle_forms_agree(golden_dir):
     assert total > 10
 
 
+def test_scripted_prey_oracle_forms_agree(golden_dir):
+    """SURVEY 8f row f3, experiments/simple_train.py:157-205 (good_agent_action / good_agent_victim_action).
+    PARITY UNPINNED: the training script holds no fixture for them and its code is not run here (DESIGN.md
+    section 4).  The serial form follows the reference text with numpy's own np.linalg.norm; the vectorised
+    form must give the same actions bit for bit on the MovingTarget trajectories, and the documented
+    properties hold: one slot per axis, capped at 1.3, pointing at the chosen corner / the target."""
+    g = _load(golden_dir, 'm_L1F4_MovingTarget')
+    spec = O.hier_spec_from_golden(g)
+    S, T = g['pos'].shape[:2]
+    corners = set()
+    for s in range(S):
+        for t in range(0, T, 3):
+            pos = g['pos'][s, t] * (2.0 if t % 2 else 1.0)             # some states outside the arena: the cap
+            env = O.SerialEnv(spec)
+            env.set_state(pos, g['vel'][s, t])
+            act, edge = O.good_agent_action_serial(env)
+            bact, bedge = O.scripted_action(spec, pos[:, :, None], -1, 0)
+            assert np.array_equal(act, bact[:, 0]) and np.array_equal(edge, bedge[:, 0])
+            corners.add(tuple(edge))
+            assert act[0] == 0 and (act >= 0).all() and act.max() <= 1.3
+            assert act[1] * act[2] == 0 and act[3] * act[4] == 0
+            want = (edge - pos[-1]) / 2
+            assert np.allclose(np.minimum(np.abs(want), 1.3), [act[1] + act[2], act[3] + act[4]], rtol=0, atol=0)
+            assert (act[1] > 0) == (want[0] > 0) and (act[3] > 0) == (want[1] > 0)
+            d = [sum(np.linalg.norm(np.array(e) - p) for p in pos[:-1]) for e in O.WORLD_EDGE]
+            assert list(edge) == O.WORLD_EDGE[int(np.argmax(d))]
+            for target in (0, 4):
+                vact = O.good_agent_victim_action_serial(env, target)
+                bv, bp = O.scripted_action(spec, pos[:, :, None], -1, 1, target)
+                assert np.array_equal(vact, bv[:, 0]) and np.array_equal(bp[:, 0], pos[target])
+                off = (pos[target] - pos[-1]) / 2
+                assert np.array_equal(np.minimum(np.abs(off) * 7, 1.3), [vact[1] + vact[2], vact[3] + vact[4]])
+    assert len(corners) >= 3
+
+
 COMM_CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec),
               ('g12_simple_crypto', O.simple_crypto_spec)]
 
