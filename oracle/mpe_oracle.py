@@ -86,6 +86,7 @@ class ScenarioSpec:
     n_food: int = 0
     n_forests: int = 0
     leader: Optional[Sequence[bool]] = None          # agent.leader (simple_world_comm.py:27): sees through forests
+    c_noise: Optional[Sequence[Optional[float]]] = None   # per agent (core.py:74,229); None -> no comm noise
 
     def __post_init__(self):
         A = self.n_agents
@@ -103,6 +104,8 @@ class ScenarioSpec:
             self.obs_r = [0.0] * A
         if self.leader is None:
             self.leader = [False] * A
+        if self.c_noise is None:
+            self.c_noise = [None] * A
         if self.advfollower is None:                 # L1F2_3Targets_100observe.py:40,52,64: the silent adversaries
             self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind in (HIER_PURSUIT, HIER_MOVING)
                                 for i in range(A)]
@@ -310,7 +313,7 @@ def simple_push_spec(n_agents=10, n_adv=9, n_landmarks=1):
 class _Body:
     __slots__ = ('is_agent', 'adversary', 'size', 'accel', 'max_speed', 'collide', 'movable',
                  'u_noise', 'mass', 'pos', 'vel', 'comm', 'u', 'c_act', 'silent', 'force_id', 'forced_id',
-                 'advleader', 'advsuperleader', 'obs_r', 'leader_force')
+                 'advleader', 'advsuperleader', 'obs_r', 'leader_force', 'c_noise')
 
 
 class SerialEnv:
@@ -330,6 +333,7 @@ class SerialEnv:
             b.collide = bool(spec.collide[e])
             b.movable = bool(spec.movable[e])
             b.u_noise = spec.u_noise[e] if b.is_agent else None
+            b.c_noise = spec.c_noise[e] if b.is_agent else None
             b.mass = spec.mass[e]
             b.pos = np.zeros(2)
             b.vel = np.zeros(2)
@@ -475,7 +479,11 @@ class SerialEnv:
             e.pos = e.pos + e.vel * s.dt
         # core.py:224-230 (all agents silent)
         for a in self.agents:
-            a.comm = np.zeros(s.dim_c) if a.silent else a.c_act + 0.0
+            if a.silent:
+                a.comm = np.zeros(s.dim_c)
+            else:
+                noise = np.random.randn(*a.c_act.shape) * a.c_noise if a.c_noise else 0.0
+                a.comm = a.c_act + noise
 
     # -- L1F*/S1L* gathers (e.g. L1F2_3Targets_100observe.py:136-253) ----------------------------------------
     def _hier_observation(self, i):
@@ -977,9 +985,9 @@ class BatchedOracle:
             return pos, vel, (lforce if lforce is not None else np.zeros((A, 2, pos.shape[-1]), T))
         return pos, vel
 
-    def comm_state(self, act):
+    def comm_state(self, act, cnoise=None):
         """agent.state.c after a step (core.py:224-230): the comm entries of the action for agents that
-        speak, zeros for silent ones.  [A, dim_c, B]."""
+        speak (+ c_noise * cnoise, standard normals [A, dim_c, B]), zeros for silent ones.  [A, dim_c, B]."""
         s, T = self.spec, self.dt
         act = np.asarray(act, dtype=T)
         if act.ndim == 3:
@@ -989,6 +997,8 @@ class BatchedOracle:
         for i in range(s.n_agents):
             if not s.silent[i]:
                 c[i] = act[offs[i] + s.comm_row0(i):offs[i] + s.comm_row0(i) + s.dim_c]
+                if s.c_noise[i] and cnoise is not None:
+                    c[i] = c[i] + np.asarray(cnoise[i], T) * T(s.c_noise[i])
         return c
 
     def _observe_comm(self, pos, vel, goal, comm):
@@ -1383,10 +1393,10 @@ class BatchedOracle:
                     info[i, 0], info[i, 1], info[i, 2], info[i, 3] = r, c, md, occ
         return obs, rew, (info if want_info else None)
 
-    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False):
+    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False, cnoise=None):
         pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True)
         obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce,
-                                      comm=self.comm_state(act) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO, WORLD_COMM) else None)
+                                      comm=self.comm_state(act, cnoise) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO, WORLD_COMM) else None)
         if return_lforce:
             return pos, vel, obs, rew, info, lforce
         return pos, vel, obs, rew, info

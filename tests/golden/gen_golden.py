@@ -295,12 +295,12 @@ COMM = {k: _load(REF + '/build/lib/multiagent/scenarios/%s.py' % k, 'ref_' + k)
                   'simple_world_comm')}                                                    # SURVEY 8f row f1, non-silent half
 
 
-def rollout_comm(kind, seeds, T, init=None):
+def rollout_comm(kind, seeds, T, init=None, c_noise=None):
     """simple_speaker_listener / simple_reference: agents that speak (comm entries in the action,
     environment.py:198-206; a non-movable agent has no physical entries, :174) and per-agent goal
     landmarks (agent.goal_b).  Actions are stored concatenated agent by agent (act_dims); `comm` is
     agent.state.c after each step; `goal` the landmark index of every agent's goal_b (-1: none)."""
-    keys = ('pos0', 'vel0', 'comm0', 'obs0', 'goal', 'act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info')
+    keys = ('pos0', 'vel0', 'comm0', 'obs0', 'goal', 'act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info', 'cnoise')
     out = {k: [] for k in keys}
     crypto = kind == 'simple_crypto'       # goal rows: (goal_a landmark, landmark whose colour is agent 2's key)
     wcomm = kind == 'simple_world_comm'    # simple_tag physics + food / forests + a speaking leader; integer info
@@ -309,6 +309,9 @@ def rollout_comm(kind, seeds, T, init=None):
         S = COMM[kind].Scenario()
         world = S.make_world()
         _shim(world)
+        if c_noise is not None:                # the scenario files carry it commented out (simple_reference.py:16)
+            for a in world.agents:
+                a.c_noise = c_noise
         # benchmark_data is broken (speaker_listener) / absent (reference); simple_crypto has one
         env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data if crypto or wcomm else None)
         obs0 = env.reset()
@@ -324,9 +327,17 @@ def rollout_comm(kind, seeds, T, init=None):
                                 for a in world.agents])
         out['comm0'].append(np.stack([np.asarray(a.state.c, float) for a in world.agents]))
         arng = np.random.RandomState(40_000 + seed)
-        ep = {k: [] for k in ('act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info')}
+        ep = {k: [] for k in ('act', 'pos', 'vel', 'comm', 'obs', 'rew', 'info', 'cnoise')}
         for t in range(T):
             parts = [arng.rand(n) for n in act_dims]
+            # core.py:229 draws randn(dim_c) per speaking agent, in agent order, from the global stream
+            s_t = 50_000 + 1000 * seed + t
+            np.random.seed(s_t)
+            speaking = [i for i, a in enumerate(world.agents) if not a.silent]
+            cn = np.zeros((len(world.agents), world.dim_c))
+            if c_noise is not None:
+                cn[speaking] = np.random.RandomState(s_t).randn(len(speaking), world.dim_c)
+            ep['cnoise'].append(cn)
             if crypto and t % 5 == 4:          # an all-zero message switches the reward terms off (:104,109,119)
                 parts[(t // 5) % 2] = np.zeros(act_dims[0])
             obs_n, rew_n, done_n, info_n = env.step([p.copy() for p in parts])
@@ -347,6 +358,9 @@ def rollout_comm(kind, seeds, T, init=None):
     res = {k: np.asarray(v) if k == 'goal' else np.stack(v) for k, v in out.items()}
     if not (crypto or wcomm):
         res.pop('info')
+    if c_noise is None:
+        res.pop('cnoise')
+    res['spec_c_noise'] = np.float64(0.0 if c_noise is None else c_noise)
     if wcomm:
         res.pop('goal')
         res['spec_n_food'], res['spec_n_forests'] = np.int64(len(world.food)), np.int64(len(world.forests))
@@ -450,6 +464,10 @@ def main():
     save('g10_simple_speaker_listener', **rollout_comm('simple_speaker_listener', range(48), 25))
     save('g11_simple_reference', **rollout_comm('simple_reference', range(48), 25))
     save('g12_simple_crypto', **rollout_comm('simple_crypto', range(48), 25))
+    # c_noise (core.py:229): no scenario file sets it (simple_reference.py:16 has it commented out)
+    save('g14_simple_reference_cnoise', **rollout_comm('simple_reference', range(16), 25, c_noise=0.1))
+    save('g14_simple_crypto_cnoise', **rollout_comm('simple_crypto', range(16), 25, c_noise=0.25))
+    save('g14_simple_world_comm_cnoise', **rollout_comm('simple_world_comm', range(16), 25, c_noise=0.1))
     save('g13_simple_world_comm', **rollout_comm('simple_world_comm', range(48), 25))
     save('g13_simple_world_comm_dense', **rollout_comm('simple_world_comm', range(24), 25, init=dense_init))
     # the fork's leader / follower / super-leader pursuit family

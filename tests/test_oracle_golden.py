@@ -477,3 +477,45 @@ def test_batched_oracle_world_comm_bit_exact(golden_dir, name):
         assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
         assert np.array_equal(info, np.moveaxis(g['info'][:, t], 0, -1))
 
+
+CNOISE_CASES = [('g14_simple_reference_cnoise', O.simple_reference_spec), ('g14_simple_crypto_cnoise', O.simple_crypto_spec),
+                ('g14_simple_world_comm_cnoise', O.simple_world_comm_spec)]
+
+
+@pytest.mark.parametrize('name,mk', CNOISE_CASES)
+def test_oracle_c_noise_bit_exact(golden_dir, name, mk):
+    """core.py:224-230 with agent.c_noise set: state.c = action.c + randn(dim_c) * c_noise, drawn per
+    speaking agent in agent order after the integration; the noisy state.c is what the other agents
+    observe and what simple_crypto scores.  Serial form (global np.random stream, seeded per step like the
+    fixture) and vectorised form (noise passed in) against the reference."""
+    import dataclasses
+    g = _load(golden_dir, name)
+    cn = float(g['spec_c_noise'])
+    spec = mk()
+    spec = dataclasses.replace(spec, c_noise=[cn] * spec.n_agents)
+    offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    S, T = g['act'].shape[:2]
+    goal = np.maximum(g['goal'].T[:spec.goal_rows], 0) if 'goal' in g.files else None
+    bo = O.BatchedOracle(spec)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    for t in range(T):
+        act = g['act'][:, t].T
+        cnz = np.moveaxis(g['cnoise'][:, t], 0, -1)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, act, goal=goal, cnoise=cnz)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1))
+        assert np.array_equal(bo.comm_state(act, cnz), np.moveaxis(g['comm'][:, t], 0, -1))
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+    assert np.abs(g['comm'][:, :, 0] - g['act'][:, :, offs[0] + spec.comm_row0(0):offs[1]]).max() > 0.05   # noise is in
+    for s in range(4):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        if goal is not None:
+            env.goals = [int(x) for x in goal[:, s]] + [0] * 3
+        for t in range(T):
+            np.random.seed(50_000 + 1000 * int(g['seeds'][s]) + t)
+            obs_n, rew_n, _, _ = env.step([g['act'][s, t, offs[i]:offs[i + 1]] for i in range(spec.n_agents)])
+            assert np.array_equal(np.stack([a.comm for a in env.agents]), g['comm'][s, t])
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]) and np.array_equal(np.asarray(rew_n, float), g['rew'][s, t])
+
