@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 4
+#define MPE_ABI_VERSION 5
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -133,6 +133,7 @@ typedef struct mpe_scenario_desc {
   int32_t n_food;
   int32_t n_forests;
   uint8_t leader[MPE_MAX_AGENTS];      /* agent.leader (simple_world_comm.py:27,261): sees everybody  */
+  double c_noise[MPE_MAX_AGENTS];      /* agent.c_noise; 0 encodes None (core.py:229)                 */
 } mpe_scenario_desc;
 
 /*
@@ -164,6 +165,8 @@ typedef struct mpe_buffers {
   void *rew;         /* [A][ld] */
   void *info;        /* [A][info_w][ld] */
   double *stats;     /* [mpe_stats_rows][mpe_stats_width] or NULL */
+  const void *cnoise; /* [A][dim_c][ld] standard normals for c_noise (core.py:229): agent.state.c = action.c +
+                         c_noise * cnoise for a speaking agent with a c_noise; NULL = no comm noise */
 } mpe_buffers;
 
 int mpe_abi_version(void);

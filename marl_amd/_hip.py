@@ -26,7 +26,7 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -53,13 +53,14 @@ class ScenarioDesc(C.Structure):
         ('advfollower', C.c_uint8 * MPE_MAX_AGENTS),
         ('n_food', C.c_int32), ('n_forests', C.c_int32),
         ('leader', C.c_uint8 * MPE_MAX_AGENTS),
+        ('c_noise', C.c_double * MPE_MAX_AGENTS),
     ]
 
 
 class Buffers(C.Structure):
     """mpe_buffers (include/mpe_hip.h): device pointers of one batch."""
     _fields_ = [(n, C.c_void_p) for n in ('act', 'noise', 'pos', 'vel', 'comm', 'lforce', 'goal', 'obs', 'rew',
-                                          'info', 'stats')]
+                                          'info', 'stats', 'cnoise')]
 
     def __init__(self, **tensors):
         super().__init__()

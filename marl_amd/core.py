@@ -169,6 +169,7 @@ class World(object):
         self.device = None
         self.dtype = None
         self.pos = self.vel = self.comm = self.act = self.noise = self.lforce = None
+        self.cnoise = None         # optional caller-supplied normals for c_noise, [A, dim_c, B]
         self.act_rows = None       # [act_total, B]: the action buffer as the kernel indexes it
         self.act_row0 = self.act_dims = None
         self.goal = None           # int32 [B]: goal landmark index (agent.goal_a), goal scenarios only
@@ -262,6 +263,7 @@ class World(object):
         self.goal = self.rows(dtype=torch.int32)   # [B]; [goal_rows, B] for scenarios with several goals (set_goal_rows)
         self.noise = None
         self._noise_buf = None
+        self._cnoise_buf = None
         self.obs = self.rew = self.info = self.obs_views = self.stats = None
         for i, e in enumerate(self.entities):
             e._world, e._index = self, i
@@ -345,6 +347,7 @@ class World(object):
         fn = getattr(_hip.lib, 'mpe_env_step_' + _hip.suffix(self.dtype))
         b = self._buf
         b.act, b.noise = self.act.data_ptr(), nptr
+        b.cnoise = self._cnoise_ptr()
         b.info = self.info.data_ptr() if (want_info and self.info.numel()) else None
         b.stats = _hip.ptr(self.stats)
         _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_env_step')
@@ -373,8 +376,7 @@ class World(object):
         d.reward_variant = int(getattr(self, 'reward_variant', 0))
         d.n_target_obs = int(getattr(self, 'n_target_obs', 3))
         for i, a in enumerate(self.agents):
-            if a.c_noise:
-                raise NotImplementedError('c_noise (core.py:229) is outside the HIP hot path')
+            d.c_noise[i] = a.c_noise if a.c_noise else 0.0            # core.py:229
             if a.action_callback is not None:
                 raise NotImplementedError('scripted agents (action_callback) are outside the HIP hot path')
             d.accel[i] = 5.0 if a.accel is None else a.accel          # environment.py:193-196
@@ -395,6 +397,19 @@ class World(object):
 
     def invalidate_descriptor(self):
         self._desc = None
+
+    def _cnoise_ptr(self):
+        """Standard normals for c_noise (core.py:229), [A, dim_c, B]: ``world.cnoise`` if the caller set it
+        (recorded draws for parity), otherwise fresh torch.randn per step.  None when nobody has a c_noise."""
+        if not any(a.c_noise and not a.silent for a in self.agents) or not self.dim_c:
+            return None
+        if self._cnoise_buf is None:
+            self._cnoise_buf = self.rows(len(self.agents), self.dim_c)
+        if self.cnoise is None:
+            self._cnoise_buf.normal_()
+        else:
+            self._cnoise_buf.copy_(self.cnoise)
+        return self._cnoise_buf.data_ptr()
 
     def _noise_ptr(self):
         """Standard normals for u_noise (core.py:147).  ``world.noise`` may be set by the caller
@@ -417,5 +432,6 @@ class World(object):
         fn = getattr(_hip.lib, 'mpe_world_step_' + _hip.suffix(self.dtype))
         b = self._buf
         b.act, b.noise = self.act.data_ptr(), nptr
+        b.cnoise = self._cnoise_ptr()
         _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_world_step')
         self.mark_dirty()

@@ -37,6 +37,7 @@ struct DevDesc {
   int32_t n_food, n_forests;            // simple_world_comm: landmarks = plain, food, forests
   uint32_t obs_lf[MPE_MAX_AGENTS / 32]; // agents whose observation carries their leader_force
   T obs_r[MPE_MAX_AGENTS];              // observation radius (the *_MovingTarget files compare distances, not squares)
+  T c_noise[MPE_MAX_AGENTS];            // agent.c_noise, 0 = None (core.py:229)
   uint32_t leader[MPE_MAX_AGENTS / 32];
   int32_t act_row0[MPE_MAX_AGENTS];  // first action row of each agent (5 rows if movable, + dim_c if not silent)
   int32_t cact_row0[MPE_MAX_AGENTS]; // first comm row inside the action (= act_row0 + 5 for a movable agent)
@@ -56,7 +57,7 @@ struct DevSizes {
 
 template <typename T>
 struct KParams {
-  const T *act, *noise;
+  const T *act, *noise, *cnoise;
   const int32_t *goal;  // per-env goal landmark index (simple_adversary / simple_push), else unused
   T *pos, *vel, *comm, *lforce, *obs, *rew, *info;
   double *stats;
@@ -297,6 +298,17 @@ __device__ __forceinline__ void leader_force(const KParams<T> &p, int a, int64_t
     lfx = lfx + fx;
     lfy = lfy + fy;
   }
+}
+
+// agent.state.c of a speaking agent as this step leaves it (core.py:226-230): the comm entries of its action,
+// plus c_noise * standard normal when the agent has a c_noise; when only observing, the comm buffer.
+template <typename T, bool DO_STEP>
+__device__ __forceinline__ T state_c(const KParams<T> &p, int a, int k, int64_t env) {
+  if (!DO_STEP) return p.comm[(int64_t)(a * p.d.dim_c + k) * p.ld + env];
+  T v = ld_stream(p.act + (int64_t)(p.d.cact_row0[a] + k) * p.ld + env);
+  if (p.cnoise != nullptr && p.d.c_noise[a] != T(0))
+    v = v + ld_stream(p.cnoise + (int64_t)(a * p.d.dim_c + k) * p.ld + env) * p.d.c_noise[a];
+  return v;
 }
 
 // np.sum(np.square(p - q)) for 2-vectors.

@@ -133,7 +133,8 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
     if (e >= h->n_agents && h->movable[e]) return MPE_ERR_UNSUPPORTED;
   }
   for (int a = 0; a < h->n_agents; ++a)
-    if (!std::isfinite(h->accel[a]) || std::isnan(h->max_speed[a]) || !std::isfinite(h->u_noise[a]))
+    if (!std::isfinite(h->accel[a]) || std::isnan(h->max_speed[a]) || !std::isfinite(h->u_noise[a]) ||
+        !std::isfinite(h->c_noise[a]))
       return MPE_ERR_DESC;
   for (int a = 0; a < h->n_agents; ++a) {
     if (h->force_id[a] < -1 || h->forced_id[a] < -1) return MPE_ERR_DESC;
@@ -300,6 +301,7 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     d.forced_id[a] = h->forced_id[a];
     d.obs_r2[a] = (T)h->obs_r[a] * (T)h->obs_r[a];
     d.obs_r[a] = (T)h->obs_r[a];
+    d.c_noise[a] = h->silent[a] ? (T)0 : (T)h->c_noise[a];
     if (observes_lforce(h, a)) d.obs_lf[a >> 5] |= 1u << (a & 31);
   }
   d.obs_total = row;
@@ -438,7 +440,9 @@ extern "C" void mpe_debug_force_tile_kernel(int on) { g_force_tile = on != 0; }
 // simple_push (10 agents) needs ~164 VGPRs in f32 (no 1024-lane workgroups) and > 256 in f64
 // (register kernel would spill: the tile kernel takes it).
 static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, SmallId *out) {
-  const SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
+  SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
+  for (int a = 0; a < h->n_agents; ++a)  // comm noise: the generic kernel only (no stock scenario sets it)
+    if (h->c_noise[a] != 0.0 && !h->silent[a]) sv = SMALL_NONE;
   if (out) *out = sv;
   if (sv == SMALL_NONE) return 0;
   if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
@@ -590,6 +594,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   if (do_step) {
     p.act = (const T *)b->act;
     p.noise = (const T *)b->noise;
+    p.cnoise = (const T *)b->cnoise;
     p.comm = (T *)b->comm;
   }
   if (do_obs) {
@@ -600,7 +605,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
     p.info = info_width_of(h) == 0 ? nullptr : (T *)b->info;  // scenario without benchmark_data
     p.stats = do_step ? b->stats : nullptr;
   }
-  if (misaligned<T>(p.act) || misaligned<T>(p.noise) || misaligned<T>(p.pos) || misaligned<T>(p.vel) ||
+  if (misaligned<T>(p.act) || misaligned<T>(p.noise) || misaligned<T>(p.cnoise) || misaligned<T>(p.pos) || misaligned<T>(p.vel) ||
       misaligned<T>(p.comm) || misaligned<T>(p.lforce) || misaligned<T>(p.obs) || misaligned<T>(p.rew) ||
       misaligned<T>(p.info) || misaligned<double>(p.stats) || misaligned<int32_t>(p.goal))
     return MPE_ERR_ALIGN;

@@ -157,8 +157,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         if (p.comm != nullptr && active) {  // core.py:226-230 (c_noise is rejected on the host)
           const bool mute = !HIER || bit(d.silent, a);
           for (int c = 0; c < d.dim_c; ++c)
-            p.comm[(int64_t)(a * d.dim_c + c) * ld + env] =
-                mute ? T(0) : ld_stream(p.act + (int64_t)(d.cact_row0[a] + c) * ld + env);
+            p.comm[(int64_t)(a * d.dim_c + c) * ld + env] = mute ? T(0) : state_c<T, DO_STEP>(p, a, c, env);
         }
       }
       __syncthreads();
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               for (int c = 0; c < d.dim_c; ++c) {
                 T v = T(0);
                 if (!bit(d.silent, 0))
-                  v = DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[0] + c) * ld + env) : p.comm[(int64_t)c * ld + env];
+                  v = state_c<T, DO_STEP>(p, 0, c, env);
                 st_stream(o, v);
                 o += ld;
               }
@@ -261,8 +260,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             if (i != 2) {
               for (int k = 0; k < C; ++k) {
-                st_stream(o, DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[2] + k) * ld + env)
-                                     : p.comm[(int64_t)(2 * C + k) * ld + env]);
+                st_stream(o, state_c<T, DO_STEP>(p, 2, k, env));
                 o += ld;
               }
             }
@@ -295,8 +293,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               for (int c = 0; c < d.dim_c; ++c) {
                 T v = T(0);
                 if (!bit(d.silent, j))
-                  v = DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[j] + c) * ld + env)
-                              : p.comm[(int64_t)(j * d.dim_c + c) * ld + env];
+                  v = state_c<T, DO_STEP>(p, j, c, env);
                 st_stream(o, v);
                 o += ld;
               }
@@ -576,8 +573,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           const int C = d.dim_c;
           const int gl = p.goal[ge];
           auto msg = [&](int a, int k) {
-            return DO_STEP ? ld_stream(p.act + (int64_t)(d.cact_row0[a] + k) * ld + ge)
-                           : p.comm[(int64_t)(a * C + k) * ld + ge];
+            return state_c<T, DO_STEP>(p, a, k, ge);
           };
           T err[2];
           bool spoke[2];

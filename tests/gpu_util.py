@@ -51,16 +51,16 @@ class HipSim:
         """mpe_buffers with the state members set, plus the given tensors."""
         return _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
 
-    def env_step(self, act, noise=None, stats=None, want_info=True, comm=None):
-        self._act, self._noise = act, noise   # keep alive until the stream has consumed them
-        b = self.buffers(act=act, noise=noise, comm=comm, obs=self.obs, rew=self.rew, stats=stats,
+    def env_step(self, act, noise=None, stats=None, want_info=True, comm=None, cnoise=None):
+        self._act, self._noise, self._cnoise = act, noise, cnoise   # keep alive until the stream has consumed them
+        b = self.buffers(act=act, noise=noise, comm=comm, cnoise=cnoise, obs=self.obs, rew=self.rew, stats=stats,
                          info=self.info if (want_info and self.info.numel()) else None)
         rc = getattr(lib, 'mpe_env_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
-    def world_step(self, act, noise=None, comm=None):
-        self._act, self._noise = act, noise
-        b = self.buffers(act=act, noise=noise, comm=comm)
+    def world_step(self, act, noise=None, comm=None, cnoise=None):
+        self._act, self._noise, self._cnoise = act, noise, cnoise
+        b = self.buffers(act=act, noise=noise, comm=comm, cnoise=cnoise)
         rc = getattr(lib, 'mpe_world_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 

@@ -23,6 +23,7 @@ def desc_from_spec(spec):
         d.obs_r[a] = spec.obs_r[a]
         d.advfollower[a] = int(spec.advfollower[a])
         d.leader[a] = int(spec.leader[a])
+        d.c_noise[a] = spec.c_noise[a] if spec.c_noise[a] else 0.0
     d.n_food, d.n_forests = spec.n_food, spec.n_forests
     d.reward_variant, d.n_target_obs = spec.reward_variant, spec.n_target_obs
     assert _hip.lib.mpe_desc_check(d) == 0

@@ -167,3 +167,70 @@ def test_reset_draws_goals_from_the_philox_oracle(mk):
     assert np.array_equal(sim.pos.cpu().numpy(), O.reset_positions(spec, 11, 4, ids))
     g = sim.goal[:spec.goal_rows].cpu().numpy()
     assert g.min() == 0 and g.max() == spec.n_landmarks - 1 and (spec.goal_rows == 1 or (g[0] != g[1]).mean() > 0.4)
+
+
+CNOISE_CASES = [('g14_simple_reference_cnoise', O.simple_reference_spec), ('g14_simple_crypto_cnoise', O.simple_crypto_spec),
+                ('g14_simple_world_comm_cnoise', O.simple_world_comm_spec)]
+
+
+@pytest.mark.parametrize('name,mk', CNOISE_CASES)
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=['f64', 'f32'])
+def test_c_noise_trajectory_matches_reference(golden_dir, name, mk, dtype, tol):
+    """agent.c_noise (core.py:229): state.c = action.c + c_noise * randn, with the reference's recorded draws
+    passed in as the cnoise buffer; the noisy state.c is what gets observed (and scored, simple_crypto).
+    A world with comm noise runs the generic tile kernel; split entry points equal the fused one."""
+    import dataclasses
+    g = _load(golden_dir, name)
+    spec = mk()
+    spec = dataclasses.replace(spec, c_noise=[float(g['spec_c_noise'])] * spec.n_agents)
+    S, T = g['act'].shape[:2]
+    goal = np.maximum(g['goal'].T[:spec.goal_rows], 0) if 'goal' in g.files else None
+    sim, two = HipSim(spec, S, dtype), HipSim(spec, S, dtype)
+    for x in (sim, two):
+        x.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'), goal)
+    for t in range(T):
+        if dtype == torch.float32 and t:                                  # teacher-forced
+            for x in (sim, two):
+                x.set_state(golden_soa(g, 'pos', t - 1), golden_soa(g, 'vel', t - 1), goal)
+        act, cn = dev(g['act'][:, t].T, dtype), dev(golden_soa(g, 'cnoise', t), dtype)
+        sim.env_step(act, comm=sim.comm, cnoise=cn)
+        two.world_step(act, comm=two.comm, cnoise=cn)
+        two.observe(comm=two.comm)
+        for x, y in zip(sim.host(), two.host()):
+            assert np.array_equal(x, y, equal_nan=True)
+        pos, vel, obs, rew, info = sim.host()
+        assert _maxerr(pos, golden_soa(g, 'pos', t)) <= tol
+        assert _maxerr(sim.comm[..., :S].double().cpu().numpy(), golden_soa(g, 'comm', t)) <= tol
+        if spec.kind == O.WORLD_COMM and dtype == torch.float32:
+            continue                                                      # thresholds: covered by test_gpu_world_comm
+        assert _maxerr(obs, g['obs'][:, t].T) <= tol
+        rerr = np.abs(rew - golden_soa(g, 'rew', t)) / np.maximum(1.0, np.abs(golden_soa(g, 'rew', t)))
+        assert rerr.max() <= tol, (name, t, rerr.max())
+    with_noise = sim.comm[0, :, :S].double().cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    clean = g['act'][:, T - 1, offs[0] + spec.comm_row0(0):offs[1]].T
+    assert np.abs(with_noise - clean).max() > 0.01                        # the noise really went in
+
+
+def test_c_noise_through_the_python_api():
+    """agent.c_noise set on a world from make_env: fresh normals every step (or world.cnoise from the caller);
+    silent agents stay at zero; without c_noise nothing changes."""
+    from marl_amd import make_env
+    B = 512
+    env = make_env('simple_reference', num_envs=B, dtype=torch.float64, seed=1)
+    env.reset()
+    w = env.world
+    for a in w.agents:
+        a.c_noise = 0.5
+    w.invalidate_descriptor()
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    action_n = [torch.rand(B, 15, generator=gen, device='cuda', dtype=torch.float64) for _ in range(2)]
+    w.cnoise = torch.full((2, 10, B), 2.0, dtype=torch.float64, device='cuda')
+    obs_n, _, _, _ = env.step(action_n)
+    assert torch.allclose(w.agents[0].state.c, action_n[0][:, 5:] + 1.0, rtol=0, atol=1e-15)
+    assert torch.equal(obs_n[1][:, -10:], w.agents[0].state.c)            # the other agent hears the noisy message
+    w.cnoise = None
+    env.step(action_n)
+    noise = (w.agents[1].state.c - action_n[1][:, 5:]) / 0.5
+    assert abs(float(noise.mean())) < 0.05 and abs(float(noise.std()) - 1.0) < 0.05
+
