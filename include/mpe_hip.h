@@ -278,6 +278,37 @@ int mpe_scripted_action_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld
                             double cap, const void *pos, void *act_out, void *point_out, void *stream);
 
 /*
+ * Replay buffer of the learner (maddpg/maddpg/trainer/replay_buffer.py; one per agent, maddpg.py:147): a ring
+ * of `capacity` transitions kept in HBM, transition-major: ring [capacity][width], one record =
+ * (obs_t | action | reward | obs_tp1 | done) concatenated (width = sum of the segment rows).
+ *
+ * mpe_replay_add: ReplayBuffer.add (:25-32) for n transitions at once, = n add() calls in env order:
+ * transition e lands in ring row (next_idx + e) % capacity; when n > capacity only the last `capacity`
+ * survive, as in the reference.  The record is gathered from `nseg` (<= 8) source segments, element (row r,
+ * transition e) of segment s at ptr[r * row_stride + e * env_stride] (SoA rows of the env kernels: row_stride
+ * = ld, env_stride = 1; a contiguous [n][rows] array: row_stride = 1, env_stride = rows).  The caller keeps
+ * len and next_idx: next_idx = (next_idx + n) % capacity, len = min(len + n, capacity).
+ *
+ * mpe_replay_gather: ReplayBuffer.sample_index (:34-44,54-55): out [batch][width] = ring[idx[b]]; idx is a
+ * DEVICE array of int64 (indices are taken modulo capacity, so a bad index cannot fault).
+ */
+typedef struct mpe_replay_seg {
+  const void *ptr;
+  int32_t rows;
+  int64_t row_stride;
+  int64_t env_stride;
+} mpe_replay_seg;
+
+int mpe_replay_add_f32(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,
+                       const mpe_replay_seg *segs, void *ring, void *stream);
+int mpe_replay_add_f64(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,
+                       const mpe_replay_seg *segs, void *ring, void *stream);
+int mpe_replay_gather_f32(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
+                          void *out, void *stream);
+int mpe_replay_gather_f64(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
+                          void *out, void *stream);
+
+/*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,
  * experiments/simple_train.py:284-286, and info_n per agent, :357).  Width = 2*A + 2 doubles:
  * [0,A) sum of reward per agent, [A,2A) sum of collisions per agent (info column 0 for

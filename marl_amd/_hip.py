@@ -78,6 +78,11 @@ class Buffers(C.Structure):
 _BUFFER_NAMES = frozenset(n for n, _ in Buffers._fields_)
 
 
+class ReplaySeg(C.Structure):
+    """mpe_replay_seg (include/mpe_hip.h): one source segment of a replay record."""
+    _fields_ = [('ptr', C.c_void_p), ('rows', C.c_int32), ('row_stride', C.c_int64), ('env_stride', C.c_int64)]
+
+
 class MpeError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -114,6 +119,10 @@ def _load():
         f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, bp, vp, vp]
         f = getattr(L, 'mpe_scripted_action_' + suf)  # desc, B, ld, agent, mode, target, cap, pos, act, point, stream
         f.restype, f.argtypes = ci, [dp, i64, i64, ci, ci, ci, C.c_double, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_replay_add_' + suf)       # capacity, next_idx, n, width, nseg, segs, ring, stream
+        f.restype, f.argtypes = ci, [i64, i64, i64, ci, ci, C.POINTER(ReplaySeg), vp, vp]
+        f = getattr(L, 'mpe_replay_gather_' + suf)    # capacity, width, idx, batch, ring, out, stream
+        f.restype, f.argtypes = ci, [i64, ci, vp, i64, vp, vp, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci]
     L.mpe_stats_reduce.restype = ci

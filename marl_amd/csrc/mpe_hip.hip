@@ -562,7 +562,7 @@ extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dty
   if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
   const int threads = small_launch_threads(h, B, dtype_bytes, nullptr);
   if (threads != 0) return (B + threads - 1) / threads;
-  return tile_grid(B, dtype_bytes == 4 ? 64 : 32);
+  return tile_grid(B, dtype_bytes == 4 ? tile_envs<float>() : tile_envs<double>());
 }
 
 template <typename T>
@@ -799,6 +799,169 @@ static int scripted_action_impl(const mpe_scenario_desc *h, int64_t B, int64_t l
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// replay buffer (maddpg/maddpg/trainer/replay_buffer.py): ring append with an SoA -> record transpose, row gather
+// ------------------------------------------------------------------------------------------------
+struct ReplaySegs {
+  const void *ptr[8];
+  int64_t row_stride[8], env_stride[8];
+  int32_t row0[9];  // first record column of each segment; row0[nseg] = width
+  int32_t nseg;
+};
+
+// One workgroup = 64 consecutive transitions; the record columns go through LDS 64 at a time: the loads
+// run along the transitions (coalesced for SoA sources), the stores along the record (each wavefront
+// writes 64 consecutive columns of one ring row).
+template <typename T>
+__global__ __launch_bounds__(256) void replay_add_kernel(int64_t capacity, int64_t next_idx, int64_t n, int64_t skip,
+                                                          int width, ReplaySegs sg, T *ring) {
+  __shared__ T tile[64][65];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t e0 = skip + (int64_t)blockIdx.x * 64;  // transitions below `skip` would be overwritten anyway
+  for (int c0 = 0; c0 < width; c0 += 64) {
+    for (int k = w; k < 64; k += 4) {  // column c0 + k (wave-uniform), transition e0 + lane
+      const int c = c0 + k;
+      if (c < width && e0 + lane < n) {
+        int s = 0;
+        while (c >= sg.row0[s + 1]) ++s;
+        const T *src = (const T *)sg.ptr[s];
+        tile[k][lane] = src[(int64_t)(c - sg.row0[s]) * sg.row_stride[s] + (e0 + lane) * sg.env_stride[s]];
+      }
+    }
+    __syncthreads();
+    for (int k = w; k < 64; k += 4) {  // transition e0 + k (wave-uniform), column c0 + lane
+      const int64_t e = e0 + k;
+      if (e < n && c0 + lane < width) ring[((next_idx + e) % capacity) * width + c0 + lane] = tile[lane][k];
+    }
+    __syncthreads();
+  }
+}
+
+// Records of up to kReplayFlatCols columns: the whole 64-transition tile sits in LDS, and since consecutive
+// transitions are consecutive ring rows the tile is one contiguous span of the ring (except at the wrap):
+// stored with a flat index, every lane busy whatever the record width.
+constexpr int kReplayFlatCols = 160;
+template <typename T>
+__global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, int64_t next_idx, int64_t n, int64_t skip,
+                                                               int width, ReplaySegs sg, T *ring) {
+  extern __shared__ __align__(16) unsigned char replay_lds[];
+  T *tile = reinterpret_cast<T *>(replay_lds);  // [width][65]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t e0 = skip + (int64_t)blockIdx.x * 64;
+  const int ne = (int)(n - e0 < 64 ? n - e0 : 64);
+  // column c (wave-uniform), transition e0 + lane; four independent loads in flight per wavefront
+  for (int c0 = w; c0 < width; c0 += 16) {
+    T v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 4 * u;
+      v[u] = T(0);
+      if (c < width && lane < ne) {
+        int s = 0;
+        while (c >= sg.row0[s + 1]) ++s;
+        const T *src = (const T *)sg.ptr[s];
+        v[u] = ld_stream(src + (int64_t)(c - sg.row0[s]) * sg.row_stride[s] + (e0 + lane) * sg.env_stride[s]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + 4 * u < width) tile[(c0 + 4 * u) * 65 + lane] = v[u];
+  }
+  __syncthreads();
+  const int total = ne * width;
+  const int64_t r0 = (next_idx + e0) % capacity;  // workgroup-uniform; the tile wraps at most once (ne <= capacity)
+  for (int f = threadIdx.x; f < total; f += 256) {
+    const int e = f / width, c = f - e * width;
+    int64_t r = r0 + e;
+    r = r >= capacity ? r - capacity : r;
+    ring[r * width + c] = tile[c * 65 + e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void replay_gather_kernel(int64_t capacity, int width, const int64_t *idx,
+                                                             int64_t total, const T *ring, T *out) {
+  // four elements per thread, 256 apart: independent index and row loads in flight
+  const int64_t blk = (int64_t)blockIdx.x * 1024;
+  const int64_t b0 = blk / width;                 // workgroup-uniform 64-bit division, once
+  const uint32_t off0 = (uint32_t)(blk - b0 * width);
+  const int64_t g0 = blk + threadIdx.x;
+  T v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t g = g0 + 256 * u;
+    v[u] = T(0);
+    if (g < total) {
+      const uint32_t t = off0 + threadIdx.x + 256u * u;  // < 1024 + width: 32-bit division
+      const uint32_t db = t / (uint32_t)width;
+      const int j = (int)(t - db * (uint32_t)width);
+      int64_t i = idx[b0 + db];
+      if ((uint64_t)i >= (uint64_t)capacity) {  // out of range: wrap instead of faulting
+        i %= capacity;
+        i = i < 0 ? i + capacity : i;
+      }
+      v[u] = ring[i * width + j];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (g0 + 256 * u < total) st_stream(out + g0 + 256 * u, v[u]);
+}
+
+template <typename T>
+static int replay_add_impl(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,
+                           const mpe_replay_seg *segs, void *ring, void *stream) {
+  if (!segs || !ring) return MPE_ERR_NULL;
+  if (capacity < 1 || next_idx < 0 || next_idx >= capacity || n < 0 || width < 1 || nseg < 1 || nseg > 8) return MPE_ERR_ARG;
+  ReplaySegs sg{};
+  int rows = 0;
+  for (int s = 0; s < nseg; ++s) {
+    if (!segs[s].ptr) return MPE_ERR_NULL;
+    if (segs[s].rows < 1) return MPE_ERR_ARG;
+    if (misaligned<T>(segs[s].ptr)) return MPE_ERR_ALIGN;
+    sg.ptr[s] = segs[s].ptr;
+    sg.row_stride[s] = segs[s].row_stride;
+    sg.env_stride[s] = segs[s].env_stride;
+    sg.row0[s] = rows;
+    rows += segs[s].rows;
+  }
+  for (int s = nseg; s <= 8; ++s) sg.row0[s] = rows;
+  sg.nseg = nseg;
+  if (rows != width) return MPE_ERR_ARG;
+  if (misaligned<T>(ring)) return MPE_ERR_ALIGN;
+  if (n == 0) return MPE_OK;
+  const int64_t skip = n > capacity ? n - capacity : 0;
+  const dim3 grid((unsigned)((n - skip + 63) / 64)), block(256);
+  if (width <= kReplayFlatCols) {
+    const size_t lds = (size_t)width * 65 * sizeof(T);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)replay_add_flat_kernel<T>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(replay_add_flat_kernel<T>, grid, block, lds, (hipStream_t)stream, capacity, next_idx, n, skip,
+                       width, sg, (T *)ring);
+  } else {
+    hipLaunchKernelGGL(replay_add_kernel<T>, grid, block, 0, (hipStream_t)stream, capacity, next_idx, n, skip, width,
+                       sg, (T *)ring);
+  }
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int replay_gather_impl(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
+                              void *out, void *stream) {
+  if (!idx || !ring || !out) return MPE_ERR_NULL;
+  if (capacity < 1 || width < 1 || batch < 0) return MPE_ERR_ARG;
+  if (misaligned<T>(ring) || misaligned<T>(out) || misaligned<int64_t>(idx)) return MPE_ERR_ALIGN;
+  if (batch == 0) return MPE_OK;
+  const int64_t total = batch * width;
+  const dim3 grid((unsigned)((total + 1023) / 1024)), block(256);
+  hipLaunchKernelGGL(replay_gather_kernel<T>, grid, block, 0, (hipStream_t)stream, capacity, width, idx, total,
+                     (const T *)ring, (T *)out);
+  return (int)hipGetLastError();
+}
+
 // One workgroup per column; rows are summed in a fixed order (thread t takes rows t, t+256, ...
 // sequentially, then a wavefront butterfly, then the 4 wavefront partials in a fixed order), so the
 // result is bitwise reproducible for a given (rows, width).
@@ -848,6 +1011,14 @@ extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, do
                                            int mode, int target, double cap, const void *pos, void *act_out,   \
                                            void *point_out, void *stream) {                                    \
     return scripted_action_impl<T>(d, B, ld, agent, mode, target, cap, pos, act_out, point_out, stream);       \
+  }                                                                                                            \
+  extern "C" int mpe_replay_add_##SUF(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,      \
+                                      const mpe_replay_seg *segs, void *ring, void *stream) {                  \
+    return replay_add_impl<T>(capacity, next_idx, n, width, nseg, segs, ring, stream);                         \
+  }                                                                                                            \
+  extern "C" int mpe_replay_gather_##SUF(int64_t capacity, int width, const int64_t *idx, int64_t batch,       \
+                                         const void *ring, void *out, void *stream) {                          \
+    return replay_gather_impl<T>(capacity, width, idx, batch, ring, out, stream);                              \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
                                  uint32_t episode, uint64_t env_id0, const uint8_t *mask,                      \

@@ -831,8 +831,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   }
 }
 
+#ifndef MPE_TILE_F32
+#define MPE_TILE_F32 64
+#endif
 template <typename T>
-constexpr int tile_envs() { return sizeof(T) == 4 ? 64 : 32; }
+constexpr int tile_envs() { return sizeof(T) == 4 ? MPE_TILE_F32 : 32; }
 
 // LDS bytes: pos rows + max(vel rows, aux rows); aux = (n_adv + NCH) int rows (tag) or L rows of T (spread).
 template <typename T>

@@ -1,0 +1,100 @@
+"""Replay buffer of the learner, kept in HBM (reference: maddpg/maddpg/trainer/replay_buffer.py; one per
+agent, maddpg.py:147,154-156).  SURVEY 8f row f4, first slice: observations never leave the GPU.
+
+Same methods as the reference class.  ``add`` takes one step of all B envs at once -- ``[B, d]`` tensors as
+``env.step`` returns them (transposed views of the kernels' SoA rows) or any other strides, ``[B]`` rewards
+and dones -- and equals B reference ``add()`` calls in env order.  Records are stored transition-major
+(``[capacity, width]``, width = obs + act + 1 + obs + 1), so ``sample_index`` is one row gather that returns
+``[batch, d]`` tensors ready for the networks.  libmpe_hip.so: mpe_replay_add_*, mpe_replay_gather_*."""
+import ctypes as C
+
+import torch
+
+from . import _hip
+
+
+class ReplayBuffer(object):
+    def __init__(self, size, device=None, dtype=torch.float32):
+        """replay_buffer.py:5-16.  ``size``: max number of transitions; old ones are overwritten."""
+        self._maxsize = int(size)
+        self._next_idx = 0
+        self._len = 0
+        self.device = torch.device('cuda' if device is None else device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('marl_amd.ReplayBuffer lives in GPU memory (no CPU fallback)')
+        self.dtype = dtype
+        self._ring = None          # [capacity, width], allocated by the first add()
+        self._dims = None          # (obs_dim, act_dim)
+
+    def __len__(self):             # :18-19
+        return self._len
+
+    def clear(self):               # :21-23
+        self._len = 0
+        self._next_idx = 0
+
+    def _seg(self, t, n):
+        """mpe_replay_seg of a [n, d] / [n] tensor with arbitrary strides."""
+        if not torch.is_tensor(t):             # e.g. the scalar False of done_n (environment.py:108)
+            t = torch.full((n,), float(t), dtype=self.dtype, device=self.device)
+        if t.dtype != self.dtype or t.device != self.device:
+            t = t.to(device=self.device, dtype=self.dtype)
+        if t.dim() == 1:
+            t = t.unsqueeze(1)
+        if t.shape[0] != n:
+            raise ValueError('expected %d transitions, got a tensor of shape %s' % (n, tuple(t.shape)))
+        return t, _hip.ReplaySeg(t.data_ptr(), t.shape[1], t.stride(1), t.stride(0))
+
+    def add(self, obs_t, action, reward, obs_tp1, done):
+        """replay_buffer.py:25-32 for one step of B envs (= B add() calls in env order)."""
+        n = reward.shape[0]
+        keep, segs = zip(*[self._seg(t, n) for t in (obs_t, action, reward, obs_tp1, done)])
+        width = sum(s.rows for s in segs)
+        if self._ring is None:
+            self._dims = (segs[0].rows, segs[1].rows)
+            self._ring = torch.zeros(self._maxsize, width, dtype=self.dtype, device=self.device)
+        elif (segs[0].rows, segs[1].rows) != self._dims or segs[3].rows != self._dims[0]:
+            raise ValueError('transition shape changed: %s' % ((segs[0].rows, segs[1].rows),))
+        arr = (_hip.ReplaySeg * 5)(*segs)
+        fn = getattr(_hip.lib, 'mpe_replay_add_' + _hip.suffix(self.dtype))
+        _hip.check(fn(self._maxsize, self._next_idx, n, width, 5, arr, self._ring.data_ptr(),
+                      _hip.stream_of(self.device)), 'mpe_replay_add')
+        self._keep = keep          # sources stay alive until the stream has consumed them
+        self._next_idx = (self._next_idx + n) % self._maxsize
+        self._len = min(self._len + n, self._maxsize)
+
+    def _encode_sample(self, idxes):
+        """replay_buffer.py:34-44: (obs [b, od], act [b, ad], rew [b], obs_next [b, od], done [b])."""
+        if not torch.is_tensor(idxes):
+            idxes = torch.as_tensor(list(idxes), dtype=torch.int64)
+        idxes = idxes.to(device=self.device, dtype=torch.int64).contiguous()
+        b = idxes.numel()
+        od, ad = self._dims
+        out = torch.empty(b, self._ring.shape[1], dtype=self.dtype, device=self.device)
+        fn = getattr(_hip.lib, 'mpe_replay_gather_' + _hip.suffix(self.dtype))
+        _hip.check(fn(self._maxsize, out.shape[1], idxes.data_ptr(), b, self._ring.data_ptr(), out.data_ptr(),
+                      _hip.stream_of(self.device)), 'mpe_replay_gather')
+        return (out[:, :od], out[:, od:od + ad], out[:, od + ad], out[:, od + ad + 1:2 * od + ad + 1],
+                out[:, 2 * od + ad + 1])
+
+    def make_index(self, batch_size):
+        """replay_buffer.py:46-47: uniform indices over the stored transitions (device tensor)."""
+        return torch.randint(0, self._len, (batch_size,), device=self.device, dtype=torch.int64)
+
+    def make_latest_index(self, batch_size):
+        """replay_buffer.py:49-52: the latest ``batch_size`` slots, shuffled."""
+        idx = (self._next_idx - 1 - torch.arange(batch_size, device=self.device, dtype=torch.int64)) % self._maxsize
+        return idx[torch.randperm(batch_size, device=self.device)]
+
+    def sample_index(self, idxes):      # :54-55
+        return self._encode_sample(idxes)
+
+    def sample(self, batch_size):       # :57-83
+        if batch_size > 0:
+            idxes = self.make_index(batch_size)
+        else:
+            idxes = torch.arange(self._len, device=self.device, dtype=torch.int64)
+        return self._encode_sample(idxes)
+
+    def collect(self):                  # :85-86
+        return self.sample(-1)
