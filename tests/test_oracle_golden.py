@@ -435,7 +435,7 @@ def test_serial_oracle_world_comm_bit_exact(golden_dir, name):
     offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
     S, T = g['act'].shape[:2]
     hidden = 0
-    for s in range(S):
+    for s in range(min(S, 16)):                          # the batched test below covers every seed
         np.random.seed(int(g['seeds'][s]))
         env = O.SerialEnv(spec, benchmark=True)
         env.reset()
