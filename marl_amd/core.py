@@ -176,6 +176,7 @@ class World(object):
         # gather outputs (allocated on first use): obs [obs_total,B], rew [A,B], info [A,W,B]
         self.obs = self.rew = self.info = None
         self.obs_views = None
+        self.obs_buffers = 2       # observation outputs alternate between this many buffers (_alloc_outputs)
         self.stats = None          # per-workgroup statistics rows (enable_stats())
         self._tick = 0             # bumped whenever the state changes
         self._gather_tick = -1     # tick the gather buffers (obs, rew, info) correspond to
@@ -282,14 +283,30 @@ class World(object):
         d = self.descriptor()
         A, B = len(self.agents), self.num_envs
         total = _hip.lib.mpe_obs_total(d)
-        self.obs = self.rows(total)
+        # Observations are double-buffered: the tensors a step returns are views of the kernel's output rows,
+        # and the reference's loops still read obs_n after the next env.step (experience(obs_n[i], ...,
+        # new_obs_n[i]), simple_train.py:284-287).  Alternating two buffers keeps the previous step's views
+        # intact for exactly that long at no extra traffic; world.obs_buffers = 1 halves the memory.
+        self._obs_pair, self._views_pair = [], []
+        for _ in range(max(1, int(self.obs_buffers))):
+            obs = self.rows(total)
+            views = []
+            for i in range(A):
+                r0, n = _hip.lib.mpe_obs_row0(d, i), _hip.lib.mpe_obs_dim(d, i)
+                views.append(obs[r0:r0 + n].t())                # [B, obs_dim_i], strides (1, ld)
+            self._obs_pair.append(obs)
+            self._views_pair.append(views)
+        self._obs_slot = 0
+        self.obs, self.obs_views = self._obs_pair[0], self._views_pair[0]
         self.rew = self.rows(A)
         self.info = self.rows(A, _hip.lib.mpe_info_width(d))
         self._buf.set(obs=self.obs, rew=self.rew)
-        self.obs_views = []
-        for i in range(A):
-            r0, n = _hip.lib.mpe_obs_row0(d, i), _hip.lib.mpe_obs_dim(d, i)
-            self.obs_views.append(self.obs[r0:r0 + n].t())      # [B, obs_dim_i], strides (1, ld)
+
+    def _flip_obs(self):
+        """Point the next observation write at the other buffer (see _alloc_outputs)."""
+        self._obs_slot = (self._obs_slot + 1) % len(self._obs_pair)
+        self.obs, self.obs_views = self._obs_pair[self._obs_slot], self._views_pair[self._obs_slot]
+        self._buf.set(obs=self.obs)
 
     def gather_obs(self):
         """Observations only (what MultiAgentEnv.reset() returns, environment.py:124-129)."""
@@ -297,6 +314,7 @@ class World(object):
             self._alloc_outputs()
         if self._gather_tick == self._tick or self._obs_tick == self._tick:
             return
+        self._flip_obs()
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
         b = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, obs=self.obs,
@@ -311,6 +329,9 @@ class World(object):
             self._alloc_outputs()
         if self._gather_tick == self._tick and not force:
             return
+        if self._obs_tick != self._tick:         # a new state: keep the previous observations intact
+            self._flip_obs()
+            self._obs_tick = self._tick
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
         b = self._buf
@@ -350,8 +371,10 @@ class World(object):
         b.cnoise = self._cnoise_ptr()
         b.info = self.info.data_ptr() if (want_info and self.info.numel()) else None
         b.stats = _hip.ptr(self.stats)
+        self._flip_obs()
         _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_env_step')
         self._tick += 1
+        self._obs_tick = self._tick
         if want_info:
             self._gather_tick = self._tick
 

@@ -448,3 +448,30 @@ def test_scripted_prey_matches_oracle_and_drives_the_env(dtype):
     far = (edge.t() - before).abs() > 0.2
     assert ((torch.sign(moved) == pull) | ~far).float().mean() > 0.9
 
+
+def test_previous_observations_survive_the_next_step():
+    """The reference's loops read obs_n after the next env.step (experience(obs_n[i], ..., new_obs_n[i]),
+    simple_train.py:284-287).  The returned tensors are views of kernel output rows; two alternating buffers
+    keep the previous step's views intact (callback path and fused path, reset included)."""
+    from marl_amd import make_env
+    B = 257
+    for kwargs in (dict(), dict(benchmark=True)):
+        env = make_env('simple_tag', num_envs=B, dtype=torch.float64, seed=0, **kwargs)
+        obs0 = env.reset()
+        keep0 = [o.clone() for o in obs0]
+        gen = torch.Generator(device='cuda').manual_seed(0)
+        act = [torch.rand(B, 5, generator=gen, device='cuda', dtype=torch.float64) for _ in range(env.n)]
+        obs1, _, _, _ = env.step(act)
+        keep1 = [o.clone() for o in obs1]
+        for a, b in zip(obs0, keep0):
+            assert torch.equal(a, b)
+        obs2, _, _, _ = env.step(act)
+        for a, b, c in zip(obs1, keep1, obs2):
+            assert torch.equal(a, b) and not torch.equal(a, c)
+        assert obs2[0].data_ptr() == obs0[0].data_ptr()                    # two buffers, alternating
+        env.world.obs_buffers = 1                                          # opt out: one buffer, half the memory
+        env.world._alloc_outputs()
+        o1, _, _, _ = env.step(act)
+        o2, _, _, _ = env.step(act)
+        assert o1[0].data_ptr() == o2[0].data_ptr()
+

@@ -68,13 +68,15 @@ def test_training_loop_shape_with_the_env():
     gen = torch.Generator(device='cuda').manual_seed(0)
     for t in range(T):
         action_n = [torch.rand(B, 5, generator=gen, device='cuda') for _ in range(env.n)]
-        prev = [o.clone() for o in obs_n]                                  # obs_n are views of buffers the step overwrites
+        want_prev = [_np(o).copy() for o in obs_n]
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
         for i in range(env.n):
-            bufs[i].add(prev[i], action_n[i], rew_n[i], new_obs_n[i], done_n[i])
+            # obs_n (from the previous step) is still intact: the env alternates two observation buffers
+            assert np.array_equal(_np(obs_n[i]), want_prev[i]) and not np.array_equal(_np(new_obs_n[i]), want_prev[i])
+            bufs[i].add(obs_n[i], action_n[i], rew_n[i], new_obs_n[i], done_n[i])
             d = done_n[i]
             d = _np(d) if torch.is_tensor(d) else np.full(B, float(d))
-            oracles[i].add_batch(_np(prev[i]), _np(action_n[i]), _np(rew_n[i]), _np(new_obs_n[i]), d)
+            oracles[i].add_batch(want_prev[i], _np(action_n[i]), _np(rew_n[i]), _np(new_obs_n[i]), d)
         obs_n = new_obs_n
     assert len(bufs[0]) == 1024 and bufs[0]._next_idx == (B * T) % 1024
     index = bufs[0].make_index(256)
