@@ -849,11 +849,12 @@ __global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t e0 = skip + (int64_t)blockIdx.x * 64;
   const int ne = (int)(n - e0 < 64 ? n - e0 : 64);
-  // column c (wave-uniform), transition e0 + lane; four independent loads in flight per wavefront
-  for (int c0 = w; c0 < width; c0 += 16) {
-    T v[4];
+  // column c (wave-uniform), transition e0 + lane; kU independent loads in flight per wavefront
+  constexpr int kU = 10;
+  for (int c0 = w; c0 < width; c0 += 4 * kU) {
+    T v[kU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const int c = c0 + 4 * u;
       v[u] = T(0);
       if (c < width && lane < ne) {
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, 
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kU; ++u)
       if (c0 + 4 * u < width) tile[(c0 + 4 * u) * 65 + lane] = v[u];
   }
   __syncthreads();
