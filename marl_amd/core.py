@@ -13,6 +13,8 @@ per-entity numpy arrays replaced by struct-of-arrays device tensors shared by al
 (strides (1, B)), so reference-style scenario code keeps working on whole batches.
 ``World.step()`` (core.py:124-140) is one HIP kernel launch (libmpe_hip.so: mpe_world_step_*).
 """
+import os
+
 import torch
 
 from . import _hip
@@ -214,7 +216,8 @@ class World(object):
         hash; measured on MI355X, simple_tag 1 Mi envs f32: 86.9 us per step at ld = B, 81.2 us at
         ld = B + 256 (B + 64: 85.5, + 2048: 84.7, + 8192: 92.2)."""
         nbytes = -(-int(num_envs) * elem_bytes // 256) * 256
-        nbytes += (1024 - nbytes) % 4096
+        pad = int(os.environ.get('MARL_AMD_ROW_PAD_BYTES', 1024))     # tuning aid; multiples of 256
+        nbytes += (pad - nbytes) % 4096
         return nbytes // elem_bytes
 
     def rows(self, *shape, dtype=None):

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, comm
   constexpr int M0 = REF ? 0 : 1;  // first moving agent (the speaker of speaker_listener is fixed)
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;
+  const int64_t blk0 = env_block() * THREADS;
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;
   // action rows: speaker_listener [c0 c1 c2 | u0..u4]; reference [u0..u4 c0..c9 | u0..u4 c0..c9]
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void crypto_kernel(const KParams<T> p) {
   constexpr int A = 3, C = 4;
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;
+  const int64_t blk0 = env_block() * THREADS;
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;
   T c[A][C];

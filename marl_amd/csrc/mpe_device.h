@@ -311,6 +311,18 @@ __device__ __forceinline__ T state_c(const KParams<T> &p, int a, int k, int64_t 
   return v;
 }
 
+// Which block of envs this workgroup owns.  Workgroups are dispatched round-robin over the 8 XCDs (each with
+// its own L2); with MPE_XCD_SWIZZLE every XCD takes one contiguous eighth of the batch instead, so that the
+// workgroups sharing an L2 write neighbouring segments of the same SoA rows.
+__device__ __forceinline__ int64_t env_block() {
+#ifdef MPE_XCD_SWIZZLE
+  const uint32_t nb = gridDim.x, b = blockIdx.x, x = b & 7u, i = b >> 3, q = nb >> 3, r = nb & 7u;
+  return (int64_t)(x * q + (x < r ? x : r) + i);
+#else
+  return (int64_t)blockIdx.x;
+#endif
+}
+
 // np.sum(np.square(p - q)) for 2-vectors.
 template <typename T>
 __device__ __forceinline__ T sqdist(T px, T py, T qx, T qy) {

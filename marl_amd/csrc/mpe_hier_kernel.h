@@ -164,7 +164,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
   static_assert(A <= 6, "counter packing holds 6 agents");
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
+  const int64_t blk0 = env_block() * THREADS;  // wave-uniform
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
   constexpr int E = A, G = A - 1;  // G: the prey
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;
+  const int64_t blk0 = env_block() * THREADS;
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);

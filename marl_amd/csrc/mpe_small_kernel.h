@@ -48,7 +48,7 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
   constexpr int ECOL = TAG ? E : ((KIND == MPE_SIMPLE_SPREAD || KIND == MPE_SIMPLE_PUSH) ? A : 0);
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;  // wave-uniform
+  const int64_t blk0 = env_block() * THREADS;  // wave-uniform
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);

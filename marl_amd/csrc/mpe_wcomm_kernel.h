@@ -18,7 +18,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 3)))
   constexpr int FOOD0 = A + 1, FOOD1 = A + 3, FOREST0 = A + 3;
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
-  const int64_t blk0 = (int64_t)blockIdx.x * THREADS;
+  const int64_t blk0 = env_block() * THREADS;
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;
   auto urow = [](int a) { return a == 0 ? 0 : 5 + C + 5 * (a - 1); };
