@@ -325,3 +325,18 @@ def test_scripted_action_argument_checks():
     d2 = _desc(O.speaker_listener_spec())
     assert lib.mpe_scripted_action_f64(d2, 8, 8, 0, 0, 0, 1.3, 8, 8, None, None) == -5   # the speaker cannot move
 
+
+
+def test_integration_md_stub_matches_the_library():
+    """The ctypes stub printed in INTEGRATION.md is what a maintainer would paste: its struct layouts must be
+    the library's (descriptor size, every mpe_buffers member)."""
+    import ctypes as C
+    from marl_amd import _hip
+    src = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    ns = {'C': C}
+    exec(src[src.index('class ScenarioDesc'):src.index('assert lib.mpe_desc_sizeof')], ns)
+    assert C.sizeof(ns['ScenarioDesc']) == _hip.lib.mpe_desc_sizeof()
+    assert [n for n, _ in ns['ScenarioDesc']._fields_] == [n for n, _ in _hip.ScenarioDesc._fields_]
+    exec(src[src.index('class Buffers'):src.index('lib.mpe_env_step_f32.argtypes')], ns)
+    assert [n for n, _ in ns['Buffers']._fields_] == [n for n, _ in _hip.Buffers._fields_]
+    assert 'mpe_abi_version() == %d' % _hip.ABI_VERSION in src
