@@ -837,36 +837,42 @@ __global__ __launch_bounds__(256) void replay_add_kernel(int64_t capacity, int64
   }
 }
 
-// Records of up to kReplayFlatCols columns: the whole 64-transition tile sits in LDS, and since consecutive
-// transitions are consecutive ring rows the tile is one contiguous span of the ring (except at the wrap):
-// stored with a flat index, every lane busy whatever the record width.
+// Records of up to kReplayFlatCols columns: the whole tile of TW transitions sits in LDS, and since
+// consecutive transitions are consecutive ring rows the tile is one contiguous span of the ring (except at
+// the wrap): stored with a flat index, every lane busy whatever the record width.  TW = 256 (each wavefront
+// loads its own 64 transitions, so a workgroup reads 1 KiB of every source row, like the env kernels) when
+// the tile fits 64 KiB of LDS, else TW = 64 (the four wavefronts share the columns).  Measured with
+// simple_tag's 39-column records, 1 Mi transitions, f32: the store phase alone 60 us with plain stores.
 constexpr int kReplayFlatCols = 160;
-template <typename T>
+template <typename T, int TW>
 __global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, int64_t next_idx, int64_t n, int64_t skip,
                                                                int width, ReplaySegs sg, T *ring) {
   extern __shared__ __align__(16) unsigned char replay_lds[];
-  T *tile = reinterpret_cast<T *>(replay_lds);  // [width][65]
+  T *tile = reinterpret_cast<T *>(replay_lds);  // [width][TW + 1]
+  constexpr int LDT = TW + 1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t e0 = skip + (int64_t)blockIdx.x * 64;
-  const int ne = (int)(n - e0 < 64 ? n - e0 : 64);
-  // column c (wave-uniform), transition e0 + lane; kU independent loads in flight per wavefront
+  const int64_t e0 = skip + (int64_t)blockIdx.x * TW;
+  const int ne = (int)(n - e0 < TW ? n - e0 : TW);
+  // column c (wave-uniform), transition e0 + el; kU independent loads in flight per wavefront
   constexpr int kU = 10;
-  for (int c0 = w; c0 < width; c0 += 4 * kU) {
+  constexpr int CSTEP = TW == 64 ? 4 : 1;           // TW == 64: wavefront w takes columns w, w + 4, ...
+  const int el = TW == 64 ? lane : 64 * w + lane;   // TW == 256: wavefront w takes transitions 64 w ..
+  for (int c0 = (TW == 64 ? w : 0); c0 < width; c0 += CSTEP * kU) {
     T v[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const int c = c0 + 4 * u;
+      const int c = c0 + CSTEP * u;
       v[u] = T(0);
-      if (c < width && lane < ne) {
+      if (c < width && el < ne) {
         int s = 0;
         while (c >= sg.row0[s + 1]) ++s;
         const T *src = (const T *)sg.ptr[s];
-        v[u] = ld_stream(src + (int64_t)(c - sg.row0[s]) * sg.row_stride[s] + (e0 + lane) * sg.env_stride[s]);
+        v[u] = ld_stream(src + (int64_t)(c - sg.row0[s]) * sg.row_stride[s] + (e0 + el) * sg.env_stride[s]);
       }
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u)
-      if (c0 + 4 * u < width) tile[(c0 + 4 * u) * 65 + lane] = v[u];
+      if (c0 + CSTEP * u < width) tile[(c0 + CSTEP * u) * LDT + el] = v[u];
   }
   __syncthreads();
   const int total = ne * width;
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, 
     const int e = f / width, c = f - e * width;
     int64_t r = r0 + e;
     r = r >= capacity ? r - capacity : r;
-    ring[r * width + c] = tile[c * 65 + e];
+    st_stream(ring + r * width + c, tile[c * LDT + e]);  // written once, read much later
   }
 }
 
@@ -932,17 +938,25 @@ static int replay_add_impl(int64_t capacity, int64_t next_idx, int64_t n, int wi
   if (misaligned<T>(ring)) return MPE_ERR_ALIGN;
   if (n == 0) return MPE_OK;
   const int64_t skip = n > capacity ? n - capacity : 0;
-  const dim3 grid((unsigned)((n - skip + 63) / 64)), block(256);
+  const dim3 block(256);
   if (width <= kReplayFlatCols) {
-    const size_t lds = (size_t)width * 65 * sizeof(T);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void *)replay_add_flat_kernel<T>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
+    const size_t lds256 = (size_t)width * 257 * sizeof(T), lds64 = (size_t)width * 65 * sizeof(T);
+    if (lds256 <= 64 * 1024 && n - skip >= 256) {
+      const dim3 grid((unsigned)((n - skip + 255) / 256));
+      hipLaunchKernelGGL((replay_add_flat_kernel<T, 256>), grid, block, lds256, (hipStream_t)stream, capacity, next_idx,
+                         n, skip, width, sg, (T *)ring);
+    } else {
+      const dim3 grid((unsigned)((n - skip + 63) / 64));
+      if (lds64 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)replay_add_flat_kernel<T, 64>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL((replay_add_flat_kernel<T, 64>), grid, block, lds64, (hipStream_t)stream, capacity, next_idx,
+                         n, skip, width, sg, (T *)ring);
     }
-    hipLaunchKernelGGL(replay_add_flat_kernel<T>, grid, block, lds, (hipStream_t)stream, capacity, next_idx, n, skip,
-                       width, sg, (T *)ring);
   } else {
+    const dim3 grid((unsigned)((n - skip + 63) / 64));
     hipLaunchKernelGGL(replay_add_kernel<T>, grid, block, 0, (hipStream_t)stream, capacity, next_idx, n, skip, width,
                        sg, (T *)ring);
   }

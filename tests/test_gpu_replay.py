@@ -23,10 +23,11 @@ def _check(rb, orb, idx):
 
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
 @pytest.mark.parametrize('capacity,B,od,ad', [(50, 7, 6, 5), (64, 16, 3, 2), (40, 100, 4, 9), (1000, 129, 70, 12),
-                                                  (300, 70, 100, 5)])
+                                                  (300, 70, 100, 5), (1000, 600, 6, 5), (5000, 777, 20, 9)])
 def test_ring_add_and_sample_match_the_oracle(dtype, capacity, B, od, ad):
     """Wrap-around, exact fill, a step larger than the whole ring, records on both kernels (up to 160 columns:
-    whole tile in LDS, flat store; wider: 64 columns per pass);
+    whole tile in LDS, flat store, 256 transitions per workgroup when a step has that many and the tile fits;
+    wider: 64 columns per pass);
     sources in every layout the loop produces: SoA row views (stride (1, ld)), contiguous [B, d], 1-D."""
     from marl_amd.replay_buffer import ReplayBuffer
     npdt = np.float64 if dtype == torch.float64 else np.float32
