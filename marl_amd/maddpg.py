@@ -1,0 +1,167 @@
+"""MADDPG learner on the batches the on-device replay buffers hand out (reference:
+maddpg/maddpg/trainer/maddpg.py, maddpg/maddpg/common/distributions.py, experiments/train_and_eval.py:94-101).
+SURVEY 8f row f4: observations, actions and rewards go from the env kernels into the replay rings and from
+there into the networks without leaving HBM.
+
+PyTorch is used here for what it is good at (small dense layers through rocBLAS / hipBLASLt, autograd, Adam);
+the data path around it (env step, replay append / gather) is the HIP library.  The reference is TensorFlow 1.x
+graph code; this module restates it function by function:
+
+    mlp_model                  train_and_eval.py:94-101   two hidden ReLU layers of num_units, linear output,
+                                                           Xavier-uniform weights / zero biases (tf.contrib.layers)
+    soft_sample                distributions.py:199-201,247-251   Gumbel-softmax relaxation per sub-space
+    p_train / q_train          maddpg.py:28-110           losses, per-variable clip_by_norm(0.5), Adam(lr)
+    make_update_exp            maddpg.py:20-26            target <- 0.99 target + 0.01 online
+    MADDPGAgentTrainer         maddpg.py:112-196          action / experience / preupdate / update
+
+*** parity unpinned ***  TensorFlow is not installed here and the reference's learner code is not run
+(DESIGN.md section 4); tests check the restated arithmetic against closed forms and that learning reduces the
+losses.  Known deviation: torch.optim.Adam adds eps outside the bias-corrected root, TF inside (eps = 1e-8).
+"""
+import torch
+from torch import nn
+
+from .replay_buffer import ReplayBuffer
+from .spaces import Discrete, MultiDiscrete
+
+
+def mlp_model(num_inputs, num_outputs, num_units=64):
+    """train_and_eval.py:94-101."""
+    net = nn.Sequential(nn.Linear(num_inputs, num_units), nn.ReLU(), nn.Linear(num_units, num_units), nn.ReLU(),
+                        nn.Linear(num_units, num_outputs))
+    for m in net:
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.zeros_(m.bias)
+    return net
+
+
+def param_sizes(act_space):
+    """Logit widths per sub-space (distributions.py:77-110): Discrete(n) -> [n]; MultiDiscrete -> high - low + 1."""
+    if isinstance(act_space, Discrete):
+        return [act_space.n]
+    if isinstance(act_space, MultiDiscrete):
+        return [int(h - l + 1) for l, h in zip(act_space.low, act_space.high)]
+    raise NotImplementedError('action space %r' % (act_space,))
+
+
+def soft_sample(flat, sizes, generator=None):
+    """SoftCategoricalPd.sample / SoftMultiCategoricalPd.sample (distributions.py:199-201,247-251):
+    softmax(logits - log(-log(u))), u ~ U[0, 1), per sub-space, concatenated (MPE's sub-spaces have low = 0)."""
+    u = torch.rand(flat.shape, device=flat.device, dtype=flat.dtype, generator=generator)
+    noisy = flat - torch.log(-torch.log(u))
+    return torch.cat([torch.softmax(part, dim=-1) for part in torch.split(noisy, sizes, dim=-1)], dim=-1)
+
+
+def clip_by_norm_(params, clip_val):
+    """tf_util.py:137-149: every variable's gradient clipped to norm clip_val on its own (tf.clip_by_norm)."""
+    for p in params:
+        if p.grad is not None:
+            norm = p.grad.norm()
+            p.grad.mul_(clip_val / torch.clamp(norm, min=clip_val))
+
+
+def polyak_update_(online, target, polyak=1.0 - 1e-2):
+    """maddpg.py:20-26."""
+    with torch.no_grad():
+        for v, vt in zip(online.parameters(), target.parameters()):
+            vt.mul_(polyak).add_(v, alpha=1.0 - polyak)
+
+
+class MADDPGAgentTrainer(object):
+    """maddpg.py:112-196, for batched envs: ``action`` maps ``[B, obs_dim]`` to ``[B, act_dim]``; ``experience``
+    appends one step of all B envs to this agent's replay ring."""
+
+    def __init__(self, name, obs_shape_n, act_space_n, agent_index, args, local_q_func=False, model=mlp_model,
+                 device='cuda', dtype=torch.float32, replay_size=1e6):
+        self.name = name
+        self.n = len(obs_shape_n)
+        self.agent_index = agent_index
+        self.args = args
+        self.local_q_func = local_q_func
+        self.device, self.dtype = torch.device(device), dtype
+        obs_dims = [int(s[0]) for s in obs_shape_n]
+        self.sizes_n = [param_sizes(sp) for sp in act_space_n]
+        act_dims = [sum(s) for s in self.sizes_n]
+        i = agent_index
+        q_in = obs_dims[i] + act_dims[i] if local_q_func else sum(obs_dims) + sum(act_dims)
+        mk = lambda a, b: model(a, b, num_units=args.num_units).to(device=self.device, dtype=dtype)
+        self.p, self.target_p = mk(obs_dims[i], act_dims[i]), mk(obs_dims[i], act_dims[i])
+        self.q, self.target_q = mk(q_in, 1), mk(q_in, 1)
+        # tf.global_variables_initializer gives the target nets their own random init (they are separate
+        # variables, maddpg.py:66,104); only the polyak updates pull them towards the online nets.
+        self.p_opt = torch.optim.Adam(self.p.parameters(), lr=args.lr, eps=1e-8)
+        self.q_opt = torch.optim.Adam(self.q.parameters(), lr=args.lr, eps=1e-8)
+        self.grad_norm_clipping = 0.5                                     # maddpg.py:130,142
+        self.replay_buffer = ReplayBuffer(replay_size, device=self.device, dtype=dtype)   # maddpg.py:147
+        self.max_replay_buffer_len = args.batch_size * args.max_episode_len
+        self.replay_sample_index = None
+
+    # -- acting ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def action(self, obs):
+        """maddpg.py:151-152 (act = a sample of the soft categorical, :45,62)."""
+        return soft_sample(self.p(obs), self.sizes_n[self.agent_index])
+
+    @torch.no_grad()
+    def target_action(self, obs):       # p_debug['target_act'], maddpg.py:70-71
+        return soft_sample(self.target_p(obs), self.sizes_n[self.agent_index])
+
+    def experience(self, obs, act, rew, new_obs, done, terminal):
+        """maddpg.py:154-156."""
+        self.replay_buffer.add(obs, act, rew, new_obs, done)
+
+    def preupdate(self):                # maddpg.py:158-159
+        self.replay_sample_index = None
+
+    # -- learning ----------------------------------------------------------------------------------
+    def _q_input(self, obs_n, act_n):
+        if self.local_q_func:           # maddpg.py:51-52,86-87
+            return torch.cat([obs_n[self.agent_index], act_n[self.agent_index]], dim=1)
+        return torch.cat(list(obs_n) + list(act_n), dim=1)
+
+    def update(self, agents, t):
+        """maddpg.py:161-196.  Returns [q_loss, p_loss, mean(target_q), mean(rew), mean(target_q_next),
+        std(target_q)] as device scalars, or None when no update is due."""
+        if len(self.replay_buffer) < self.max_replay_buffer_len:          # :162
+            return None
+        if not t % 100 == 0:                                              # :164
+            return None
+        self.replay_sample_index = self.replay_buffer.make_index(self.args.batch_size)
+        index = self.replay_sample_index
+        obs_n, obs_next_n, act_n = [], [], []
+        for i in range(self.n):                                           # :173-177
+            obs, act, rew, obs_next, done = agents[i].replay_buffer.sample_index(index)
+            obs_n.append(obs)
+            obs_next_n.append(obs_next)
+            act_n.append(act)
+        obs, act, rew, obs_next, done = self.replay_buffer.sample_index(index)
+
+        with torch.no_grad():                                             # :181-187 (num_sample = 1)
+            target_act_next_n = [agents[i].target_action(obs_next_n[i]) for i in range(self.n)]
+            target_q_next = self.target_q(self._q_input(obs_next_n, target_act_next_n))[:, 0]
+            target_q = rew + self.args.gamma * (1.0 - done) * target_q_next
+
+        # q_train (:75-110): mean squared Bellman error
+        q = self.q(self._q_input(obs_n, act_n))[:, 0]
+        q_loss = torch.mean(torch.square(q - target_q))
+        self.q_opt.zero_grad(set_to_none=True)
+        q_loss.backward()
+        clip_by_norm_(self.q.parameters(), self.grad_norm_clipping)
+        self.q_opt.step()
+
+        # p_train (:28-73): -mean Q with this agent's action replaced by a fresh sample, + 1e-3 mean(logits^2)
+        logits = self.p(obs_n[self.agent_index])
+        act_input_n = list(act_n)
+        act_input_n[self.agent_index] = soft_sample(logits, self.sizes_n[self.agent_index])
+        pg_loss = -torch.mean(self.q(self._q_input(obs_n, act_input_n))[:, 0])
+        p_loss = pg_loss + torch.mean(torch.square(logits)) * 1e-3
+        self.p_opt.zero_grad(set_to_none=True)
+        p_loss.backward()                                                 # only p's variables are stepped (:58)
+        clip_by_norm_(self.p.parameters(), self.grad_norm_clipping)
+        self.p_opt.step()
+        self.q_opt.zero_grad(set_to_none=True)
+
+        polyak_update_(self.p, self.target_p)                             # :193-194
+        polyak_update_(self.q, self.target_q)
+        return [q_loss.detach(), p_loss.detach(), target_q.mean(), rew.mean(), target_q_next.mean(), target_q.std(unbiased=False)]

@@ -1,0 +1,144 @@
+"""MADDPG learner (reference maddpg/maddpg/trainer/maddpg.py, common/distributions.py).
+PARITY UNPINNED: TensorFlow is not installed and the reference's learner code is not run here (DESIGN.md
+section 4).  CPU tests pin the restated pieces to closed forms; GPU tests run the trainer on the env + replay
+data path and check that the updates do what the reference's text says."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from marl_amd import spaces
+from marl_amd.maddpg import clip_by_norm_, mlp_model, param_sizes, polyak_update_, soft_sample
+
+
+def test_param_sizes_follow_the_action_spaces():
+    assert param_sizes(spaces.Discrete(5)) == [5]
+    assert param_sizes(spaces.MultiDiscrete([[0, 4], [0, 6]])) == [5, 7]      # a leader: 5 physical + 7 commands
+
+
+def test_soft_sample_is_a_gumbel_softmax_per_sub_space():
+    g = torch.Generator().manual_seed(0)
+    flat = torch.randn(4096, 12, dtype=torch.float64)
+    out = soft_sample(flat, [5, 7], generator=g)
+    assert out.shape == flat.shape and (out >= 0).all()
+    assert torch.allclose(out[:, :5].sum(1), torch.ones(4096, dtype=torch.float64))
+    assert torch.allclose(out[:, 5:].sum(1), torch.ones(4096, dtype=torch.float64))
+    g = torch.Generator().manual_seed(0)                                    # closed form with the same uniforms
+    u = torch.rand(flat.shape, dtype=torch.float64, generator=g)
+    want = torch.softmax((flat - torch.log(-torch.log(u)))[:, :5], dim=-1)
+    assert torch.equal(out[:, :5], want)
+    # argmax of the relaxed sample is distributed like softmax(logits) (the Gumbel-max trick)
+    logits = torch.tensor([1.0, 0.0, -1.0, 0.5, 0.0], dtype=torch.float64).expand(200000, 5)
+    freq = torch.bincount(soft_sample(logits, [5]).argmax(1), minlength=5).double() / 200000
+    assert torch.allclose(freq, torch.softmax(logits[0], 0), atol=5e-3)
+
+
+def test_clip_by_norm_is_per_variable():
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+    a.grad, b.grad = torch.tensor([3.0, 4.0, 0.0]), torch.tensor([0.3, 0.0])
+    clip_by_norm_([a, b], 0.5)                                              # tf.clip_by_norm: g * clip / max(|g|, clip)
+    assert torch.allclose(a.grad, torch.tensor([0.3, 0.4, 0.0])) and torch.allclose(b.grad, torch.tensor([0.3, 0.0]))
+
+
+def test_polyak_update_and_model_shape():
+    torch.manual_seed(0)
+    online, target = mlp_model(6, 3, num_units=8), mlp_model(6, 3, num_units=8)
+    assert [tuple(p.shape) for p in online.parameters()] == [(8, 6), (8,), (8, 8), (8,), (3, 8), (3,)]
+    assert all((m.bias == 0).all() for m in online if isinstance(m, torch.nn.Linear))
+    w0, t0 = online[0].weight.detach().clone(), target[0].weight.detach().clone()
+    polyak_update_(online, target)
+    assert torch.allclose(target[0].weight, 0.99 * t0 + 0.01 * w0)          # maddpg.py:21-24
+    assert torch.equal(online[0].weight, w0)
+
+
+def _args(**kw):
+    d = dict(lr=1e-2, gamma=0.95, batch_size=256, num_units=64, max_episode_len=25)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scenario', ['simple_spread', 'S1L2F2_3Targets_100observe'])
+def test_training_loop_runs_on_device_and_learns_the_critic(scenario):
+    """The reference's loop shape (simple_train.py:257-300): act, step, experience, update; everything stays
+    on the GPU.  The critic's Bellman error on a held batch falls over the updates; targets follow by polyak."""
+    from marl_amd import make_env
+    from marl_amd.maddpg import MADDPGAgentTrainer
+    torch.manual_seed(0)
+    B = 512
+    env = make_env(scenario, num_envs=B, dtype=torch.float32, seed=1)
+    args = _args(batch_size=256, max_episode_len=4)
+    obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
+    trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args) for i in range(env.n)]
+    obs_n = env.reset()
+    losses, t = [], 0
+    tp0 = trainers[0].target_q[0].weight.detach().clone()
+    for step in range(1, 1201):
+        action_n = [tr.action(obs) for tr, obs in zip(trainers, obs_n)]
+        for a, sp in zip(action_n, env.action_space):
+            assert a.shape == (B, sum(param_sizes(sp))) and a.is_cuda
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        if step % 10 == 0:                                                # keep the test short: store every 10th step
+            for i, tr in enumerate(trainers):
+                tr.experience(obs_n[i], action_n[i], rew_n[i], new_obs_n[i], done_n[i], False)
+        obs_n = new_obs_n
+        if step % 25 == 0:
+            obs_n = env.reset()
+        t += 1
+        for tr in trainers:
+            tr.preupdate()
+        for tr in trainers:
+            out = tr.update(trainers, t)
+            if out is not None and tr is trainers[0]:
+                losses.append([float(x) for x in out])
+    assert len(losses) == 12                                              # every 100 steps (maddpg.py:164)
+    assert all(np.isfinite(l).all() for l in losses)
+    assert not torch.equal(trainers[0].target_q[0].weight, tp0)           # targets moved
+    assert len(trainers[0].replay_buffer) == 120 * B
+
+
+@pytest.mark.gpu
+def test_update_follows_the_reference_arithmetic():
+    """One update on a hand-filled buffer: target_q = rew + gamma (1 - done) Q'(o', a'~pi'), q_loss = mean
+    squared error before the step; local_q_func (ddpg) only sees the agent's own obs and action."""
+    from marl_amd.maddpg import MADDPGAgentTrainer
+    torch.manual_seed(3)
+    args = _args(batch_size=64, max_episode_len=1)
+    obs_shape_n, act_space_n = [(6,), (4,)], [spaces.Discrete(5), spaces.MultiDiscrete([[0, 4], [0, 2]])]
+    tr = [MADDPGAgentTrainer('a%d' % i, obs_shape_n, act_space_n, i, args, local_q_func=(i == 1)) for i in range(2)]
+    assert tr[0].q[0].in_features == 6 + 4 + 5 + 8 and tr[1].q[0].in_features == 4 + 8
+    n = 64
+    data = []
+    for i, (od, ad) in enumerate(((6, 5), (4, 8))):
+        obs, act, nxt = torch.rand(n, od, device='cuda'), torch.rand(n, ad, device='cuda'), torch.rand(n, od, device='cuda')
+        rew, done = torch.randn(n, device='cuda'), (torch.rand(n, device='cuda') < 0.3).float()
+        tr[i].experience(obs, act, rew, nxt, done, False)
+        data.append((obs, act, rew, nxt, done))
+    assert tr[0].update(tr, 3) is None                                    # not a multiple of 100
+    q0 = [p.detach().clone() for p in tr[0].q.parameters()]
+    p0 = [p.detach().clone() for p in tr[0].p.parameters()]
+    tq0 = [p.detach().clone() for p in tr[0].target_q.parameters()]
+    q_loss, p_loss, mean_tq, mean_rew, mean_tqn, std_tq = [float(x) for x in tr[0].update(tr, 100)]
+    idx = tr[0].replay_sample_index
+    assert idx.shape == (64,) and int(idx.max()) < n
+    rew, done = data[0][2][idx], data[0][4][idx]
+    assert mean_rew == pytest.approx(float(rew.mean()), rel=1e-6)
+    assert q_loss >= 0 and np.isfinite([q_loss, p_loss, std_tq, mean_tqn]).all()
+    assert any(not torch.equal(a, b) for a, b in zip(q0, tr[0].q.parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(p0, tr[0].p.parameters()))
+    for a, b, c in zip(tq0, tr[0].target_q.parameters(), tr[0].q.parameters()):
+        assert torch.allclose(b, 0.99 * a + 0.01 * c, atol=1e-7)          # polyak after the step (maddpg.py:193-194)
+    # with every transition terminal the target is the reward itself
+    for i in range(2):
+        tr[i].replay_buffer.clear()
+        obs, act, rew, nxt, _ = data[i]
+        tr[i].experience(obs, act, rew, nxt, torch.ones(n, device='cuda'), False)
+    import copy
+    critic = copy.deepcopy(tr[1].q)                                       # the critic before the step
+    out = [float(x) for x in tr[1].update(tr, 200)]
+    assert out[2] == pytest.approx(out[3], rel=1e-6)                       # mean(target_q) == mean(rew)
+    idx = tr[1].replay_sample_index
+    with torch.no_grad():                                                 # ddpg critic: own obs and action only
+        q = critic(torch.cat([data[1][0][idx], data[1][1][idx]], 1))[:, 0]
+    assert out[0] == pytest.approx(float(torch.mean((q - data[1][2][idx]) ** 2)), rel=1e-5)
