@@ -1,0 +1,52 @@
+"""The reference's training loop shape (experiments/simple_train.py:257-300) entirely on one GPU: batched env
+step -> per-agent replay rings -> MADDPG updates every 100 steps.  Prints agent-steps/s with the learner in the
+loop (run on the GPU box from the repo root):
+    python tools/train_demo.py [scenario] [num_envs] [steps]"""
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from marl_amd import make_env  # noqa: E402
+from marl_amd.maddpg import MADDPGAgentTrainer  # noqa: E402
+
+
+def main():
+    scenario = sys.argv[1] if len(sys.argv) > 1 else 'simple_tag'
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 16
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+    args = types.SimpleNamespace(lr=1e-2, gamma=0.95, batch_size=1024, num_units=64, max_episode_len=25)
+    env = make_env(scenario, num_envs=B, dtype=torch.float32, seed=0)
+    obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
+    trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=1 << 22)
+                for i in range(env.n)]
+    obs_n = env.reset()
+    t0 = None
+    for t in range(1, steps + 101):
+        if t == 101:                                    # 100 warm-up steps, incl. the first update
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        action_n = [tr.action(obs) for tr, obs in zip(trainers, obs_n)]
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+        for i, tr in enumerate(trainers):
+            tr.experience(obs_n[i], action_n[i], rew_n[i], new_obs_n[i], done_n[i], t % 25 == 0)
+        obs_n = new_obs_n
+        if t % 25 == 0:
+            obs_n = env.reset()
+        for tr in trainers:
+            tr.preupdate()
+        for tr in trainers:
+            out = tr.update(trainers, t)
+        if out is not None:
+            print('step %5d  q_loss %.4f  p_loss %.4f  mean reward %.3f' % (t, float(out[0]), float(out[1]), float(out[3])))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print('%s: %d envs x %d steps with %d learners in the loop: %.1f ms/step, %.3e agent-steps/s'
+          % (scenario, B, steps, env.n, 1e3 * dt / steps, B * env.n * steps / dt))
+
+
+if __name__ == '__main__':
+    main()
