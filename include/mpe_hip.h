@@ -309,6 +309,24 @@ int mpe_replay_gather_f64(int64_t capacity, int width, const int64_t *idx, int64
                           void *out, void *stream);
 
 /*
+ * Actor forward of the learner for every env in one launch (maddpg/maddpg/trainer/maddpg.py:39-45,151-152;
+ * model experiments/train_and_eval.py:94-101; sample common/distributions.py:199-201,247-251):
+ *     act = softmax_per_sub_space(W3 relu(W2 relu(W1 obs + b1) + b2) + b3 - log(-log(u)))
+ * with MPE_ACTOR_HIDDEN = 64 units per hidden layer and one (Discrete: s1 = 0) or two (MultiDiscrete) sub-spaces
+ * of s0 / s1 logits, s0 + s1 <= MPE_ACTOR_MAX_OUT.  obs [in_dim][ld_obs] are the SoA observation rows of the
+ * agent (mpe_obs_row0), act [s0 + s1][ld_act] SoA action rows (e.g. the agent's rows of the action buffer,
+ * mpe_act_row0).  weights: packed f32 device array W1t [in_dim][64], b1 [64], W2t [64][64], b2 [64],
+ * W3t [64][16], b3 [16] (t = transposed: input index first; columns >= s0 + s1 zero).  u: [s0 + s1][ld_act]
+ * uniforms in (0, 1), or NULL = Philox4x32-10 with counter (env_id_lo, env_id_hi, call_counter, 0xC0000000 |
+ * word group) and key = seed.  f32 only (the reference's networks are float32).
+ */
+#define MPE_ACTOR_HIDDEN 64
+#define MPE_ACTOR_MAX_OUT 16
+int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0, int s1, const void *obs,
+                          const void *weights, const void *u, uint64_t seed, uint32_t call_counter, uint64_t env_id0,
+                          void *act, void *stream);
+
+/*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,
  * experiments/simple_train.py:284-286, and info_n per agent, :357).  Width = 2*A + 2 doubles:
  * [0,A) sum of reward per agent, [A,2A) sum of collisions per agent (info column 0 for

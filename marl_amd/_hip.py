@@ -123,6 +123,9 @@ def _load():
         f.restype, f.argtypes = ci, [i64, i64, i64, ci, ci, C.POINTER(ReplaySeg), vp, vp]
         f = getattr(L, 'mpe_replay_gather_' + suf)    # capacity, width, idx, batch, ring, out, stream
         f.restype, f.argtypes = ci, [i64, ci, vp, i64, vp, vp, vp]
+    # B, ld_obs, ld_act, in_dim, s0, s1, obs, weights, u, seed, call_counter, env_id0, act, stream
+    L.mpe_actor_forward_f32.restype = ci
+    L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci]
     L.mpe_stats_reduce.restype = ci

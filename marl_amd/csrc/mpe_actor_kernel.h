@@ -1,0 +1,111 @@
+// Fused actor forward of the MADDPG learner (maddpg/maddpg/trainer/maddpg.py:39-45,151-152 with the model of
+// experiments/train_and_eval.py:94-101 and the sample of common/distributions.py:199-201,247-251):
+//
+//     logits = W3 relu(W2 relu(W1 obs + b1) + b2) + b3        two hidden layers of 64 units
+//     action = softmax(logits - log(-log(u))) per sub-space    u ~ U(0, 1): Gumbel-softmax relaxation
+//
+// for every env in one launch, reading the env kernels' SoA observation rows and writing SoA action rows (the
+// rows env_step reads next), so an acting step moves 4 (in + out) bytes per env and nothing else.  One env per
+// lane: the 64 + 64 hidden activations live in VGPRs, the weights are wave-uniform (layer 1 through the scalar
+// cache as SGPR operands of v_fmac, layers 2 / 3 as LDS broadcast reads), so the inner loops are pure VALU: 2 (in 64 + 64 64 + 64 out) flop
+// per env.  Dense but tiny: at 64 units the whole problem is 11 GFLOP per million envs -- f32 VALU work for
+// ~0.1 ms, not worth an MFMA tiling (fp32 MFMA has the vector rate anyway); f32 because the reference's
+// networks are.  Packed weights (host side, marl_amd/maddpg.py:pack_actor): W1t [in][64], b1 [64], W2t [64][64],
+// b2 [64], W3t [64][16], b3 [16], output columns beyond s0 + s1 zero.
+#pragma once
+#include "mpe_device.h"
+
+namespace mpe {
+
+constexpr int kActorHidden = 64;
+constexpr int kActorMaxOut = 16;
+
+__global__ __launch_bounds__(256) void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0,
+                                                            int s1, const float *__restrict__ obs,
+                                                            const float *__restrict__ wts, const float *__restrict__ u,
+                                                            uint32_t k0, uint32_t k1, uint32_t counter, uint64_t env_id0,
+                                                            float *__restrict__ act) {
+  constexpr int H = kActorHidden, O = kActorMaxOut;
+  const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool active = env < B;
+  const int64_t ge = active ? env : B - 1;  // tail lanes shadow the last env, their stores are skipped
+  const float *W1 = wts, *b1 = W1 + (int64_t)in_dim * H, *W2 = b1 + H;
+  // The 5 200 weights of layers 2 and 3 go through LDS (uniform address = broadcast read).
+  __shared__ float sW[H * H + H + H * O + O];
+  for (int t = threadIdx.x; t < H * H + H + H * O + O; t += 256) sW[t] = W2[t];  // W2, b2, W3, b3 are contiguous
+  __syncthreads();
+  const float *sW2 = sW, *sb2 = sW + H * H, *sW3 = sb2 + H, *sb3 = sW3 + H * O;
+  float h1[H], out[O];
+#pragma unroll
+  for (int j = 0; j < H; ++j) h1[j] = b1[j];
+  for (int i = 0; i < in_dim; ++i) {  // one coalesced row load per input, 64 FMAs with scalar weights
+    const float x = ld_stream(obs + (int64_t)i * ld_obs + ge);
+    const float *w = W1 + (int64_t)i * H;
+#pragma unroll
+    for (int j = 0; j < H; ++j) h1[j] = fmaf(w[j], x, h1[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < H; ++j) h1[j] = h1[j] > 0.0f ? h1[j] : 0.0f;
+#pragma unroll
+  for (int m = 0; m < O; ++m) out[m] = sb3[m];
+  // layer 2 in blocks of KB output units (j unrolled: static h1 registers), each block folded into layer 3 at
+  // once, so h2 never exists as an array; the block loop stays a real loop, which bounds what the scheduler
+  // may hoist (fully unrolled, it pulls all 5 200 weight reads to the top and spills)
+  constexpr int KB = 8;
+#pragma unroll 1
+  for (int kb = 0; kb < H; kb += KB) {
+    float acc[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) acc[kk] = sb2[kb + kk];
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) acc[kk] = fmaf(sW2[j * H + kb + kk], h1[j], acc[kk]);
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const float a = acc[kk] > 0.0f ? acc[kk] : 0.0f;
+#pragma unroll
+      for (int m = 0; m < O; ++m) out[m] = fmaf(sW3[(kb + kk) * O + m], a, out[m]);
+    }
+  }
+  // Gumbel noise: caller-supplied uniforms (tests, replaying a recorded draw) or Philox4x32-10 keyed like the
+  // reset stream: counter (env_lo, env_hi, call counter, 0xC0000000 | word group), key = seed
+  const int nout = s0 + s1;
+  float g[O];
+  if (u != nullptr) {
+#pragma unroll
+    for (int m = 0; m < O; ++m) g[m] = m < nout ? ld_stream(u + (int64_t)m * ld_act + ge) : 0.5f;
+  } else {
+    const uint64_t gid = env_id0 + (uint64_t)ge;
+#pragma unroll
+    for (int q = 0; q < O / 4; ++q) {
+      uint32_t w[4];
+      philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), counter, 0xC0000000u | (uint32_t)q, k0, k1, w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[4 * q + r] = ((float)(w[r] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+    }
+  }
+  float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+  for (int m = 0; m < O; ++m) {
+    out[m] = out[m] - __logf(-__logf(g[m]));
+    mx0 = (m < s0 && out[m] > mx0) ? out[m] : mx0;
+    mx1 = (m >= s0 && m < nout && out[m] > mx1) ? out[m] : mx1;
+  }
+  float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+  for (int m = 0; m < O; ++m) {
+    const float e = __expf(out[m] - (m < s0 ? mx0 : mx1));
+    out[m] = e;
+    z0 += m < s0 ? e : 0.0f;
+    z1 += (m >= s0 && m < nout) ? e : 0.0f;
+  }
+  const float r0 = 1.0f / z0, r1 = 1.0f / z1;
+  if (active) {
+#pragma unroll
+    for (int m = 0; m < O; ++m)
+      if (m < nout) st_stream(act + (int64_t)m * ld_act + env, out[m] * (m < s0 ? r0 : r1));
+  }
+}
+
+}  // namespace mpe

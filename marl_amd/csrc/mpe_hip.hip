@@ -9,6 +9,7 @@
 #include "mpe_device.h"
 #include "mpe_comm_kernel.h"
 #include "mpe_wcomm_kernel.h"
+#include "mpe_actor_kernel.h"
 #include "mpe_hier_kernel.h"
 #include "mpe_small_kernel.h"
 #include "mpe_tile_kernel.h"
@@ -974,6 +975,21 @@ static int replay_gather_impl(int64_t capacity, int width, const int64_t *idx, i
   const dim3 grid((unsigned)((total + 1023) / 1024)), block(256);
   hipLaunchKernelGGL(replay_gather_kernel<T>, grid, block, 0, (hipStream_t)stream, capacity, width, idx, total,
                      (const T *)ring, (T *)out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0, int s1,
+                                     const void *obs, const void *weights, const void *u, uint64_t seed,
+                                     uint32_t call_counter, uint64_t env_id0, void *act, void *stream) {
+  if (!obs || !weights || !act) return MPE_ERR_NULL;
+  if (B < 1 || ld_obs < B || ld_act < B) return MPE_ERR_BATCH;
+  if (in_dim < 1 || in_dim > 4096 || s0 < 1 || s1 < 0 || s0 + s1 > kActorMaxOut) return MPE_ERR_ARG;
+  if (misaligned<float>(obs) || misaligned<float>(weights) || misaligned<float>(u) || misaligned<float>(act))
+    return MPE_ERR_ALIGN;
+  const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+  hipLaunchKernelGGL(actor_forward_kernel, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, in_dim, s0, s1,
+                     (const float *)obs, (const float *)weights, (const float *)u, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), call_counter, env_id0, (float *)act);
   return (int)hipGetLastError();
 }
 

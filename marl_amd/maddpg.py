@@ -53,6 +53,45 @@ def soft_sample(flat, sizes, generator=None):
     return torch.cat([torch.softmax(part, dim=-1) for part in torch.split(noisy, sizes, dim=-1)], dim=-1)
 
 
+ACTOR_HIDDEN, ACTOR_MAX_OUT = 64, 16       # MPE_ACTOR_HIDDEN / MPE_ACTOR_MAX_OUT (include/mpe_hip.h)
+
+
+def pack_actor(net):
+    """The packed f32 weight array mpe_actor_forward_f32 reads (include/mpe_hip.h): W1t [in][64], b1 [64],
+    W2t [64][64], b2 [64], W3t [64][16], b3 [16]; or None when ``net`` is not the stock 2 x 64 model."""
+    lin = [m for m in net if isinstance(m, nn.Linear)] if isinstance(net, nn.Sequential) else []
+    if (len(lin) != 3 or len(net) != 5 or lin[0].out_features != ACTOR_HIDDEN or lin[1].out_features != ACTOR_HIDDEN
+            or lin[2].out_features > ACTOR_MAX_OUT or lin[0].weight.dtype != torch.float32):
+        return None
+    w3 = torch.zeros(ACTOR_HIDDEN, ACTOR_MAX_OUT, device=lin[2].weight.device)
+    b3 = torch.zeros(ACTOR_MAX_OUT, device=lin[2].weight.device)
+    w3[:, :lin[2].out_features] = lin[2].weight.detach().t()
+    b3[:lin[2].out_features] = lin[2].bias.detach()
+    return torch.cat([lin[0].weight.detach().t().reshape(-1), lin[0].bias.detach(), lin[1].weight.detach().t().reshape(-1),
+                      lin[1].bias.detach(), w3.reshape(-1), b3]).contiguous()
+
+
+def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0):
+    """One launch of libmpe_hip.so:mpe_actor_forward_f32.  ``obs``: ``[B, in_dim]`` view of SoA rows (strides
+    (1, ld)), as env.step returns it.  Returns the action as the same kind of view (``[B, sum(sizes)]`` over SoA rows
+    with the same ld), which env.step adopts without a copy.  ``u``: optional ``[B, sum(sizes)]`` uniforms (same
+    layout) instead of the kernel's own Philox draw."""
+    from . import _hip
+    B, in_dim = obs.shape
+    ld = obs.stride(1) if in_dim > 1 else B
+    nout = sum(sizes)
+    act = torch.empty(nout, ld, dtype=torch.float32, device=obs.device)
+    if u is not None and (u.stride(0) != 1 or (nout > 1 and u.stride(1) != ld)):
+        uu = torch.empty(nout, ld, dtype=torch.float32, device=obs.device)
+        uu[:, :B] = u.t()
+        u = uu[:, :B].t()
+    s0, s1 = sizes[0], (sizes[1] if len(sizes) > 1 else 0)
+    _hip.check(_hip.lib.mpe_actor_forward_f32(B, ld, ld, in_dim, s0, s1, obs.data_ptr(), packed.data_ptr(),
+                                              None if u is None else u.data_ptr(), seed, call_counter, env_id0,
+                                              act.data_ptr(), _hip.stream_of(obs.device)), 'mpe_actor_forward')
+    return act[:, :B].t()
+
+
 def clip_by_norm_(params, clip_val):
     """tf_util.py:137-149: every variable's gradient clipped to norm clip_val on its own (tf.clip_by_norm)."""
     for p in params:
@@ -96,12 +135,27 @@ class MADDPGAgentTrainer(object):
         self.replay_buffer = ReplayBuffer(replay_size, device=self.device, dtype=dtype)   # maddpg.py:147
         self.max_replay_buffer_len = args.batch_size * args.max_episode_len
         self.replay_sample_index = None
+        self._packed = None            # packed actor weights for the fused kernel; dropped by every update
+        self._act_calls = 0
+        self.seed = 0x5EED0000 + agent_index
 
     # -- acting ------------------------------------------------------------------------------------
     @torch.no_grad()
     def action(self, obs):
-        """maddpg.py:151-152 (act = a sample of the soft categorical, :45,62)."""
-        return soft_sample(self.p(obs), self.sizes_n[self.agent_index])
+        """maddpg.py:151-152 (act = a sample of the soft categorical, :45,62).  Observations that are views of
+        the env kernels' SoA rows go through the fused HIP kernel (network + Gumbel-softmax in one launch,
+        mpe_actor_forward_f32); anything else (other layouts, models, dtypes) through the same arithmetic in
+        torch on the GPU."""
+        sizes = self.sizes_n[self.agent_index]
+        if (obs.dim() == 2 and obs.dtype == torch.float32 and obs.is_cuda and obs.stride(0) == 1
+                and (obs.shape[1] == 1 or obs.stride(1) >= obs.shape[0]) and len(sizes) <= 2
+                and sum(sizes) <= ACTOR_MAX_OUT):
+            if self._packed is None:
+                self._packed = pack_actor(self.p)
+            if self._packed is not None:
+                self._act_calls += 1
+                return actor_forward(self._packed, obs, sizes, seed=self.seed, call_counter=self._act_calls)
+        return soft_sample(self.p(obs), sizes)
 
     @torch.no_grad()
     def target_action(self, obs):       # p_debug['target_act'], maddpg.py:70-71
@@ -160,6 +214,7 @@ class MADDPGAgentTrainer(object):
         p_loss.backward()                                                 # only p's variables are stepped (:58)
         clip_by_norm_(self.p.parameters(), self.grad_norm_clipping)
         self.p_opt.step()
+        self._packed = None
         self.q_opt.zero_grad(set_to_none=True)
 
         polyak_update_(self.p, self.target_p)                             # :193-194

@@ -142,3 +142,41 @@ def test_update_follows_the_reference_arithmetic():
     with torch.no_grad():                                                 # ddpg critic: own obs and action only
         q = critic(torch.cat([data[1][0][idx], data[1][1][idx]], 1))[:, 0]
     assert out[0] == pytest.approx(float(torch.mean((q - data[1][2][idx]) ** 2)), rel=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('in_dim,sizes', [(16, [5]), (34, [5, 4]), (20, [5, 7]), (3, [3]), (11, [5, 10]), (244, [5])])
+def test_fused_actor_kernel_matches_torch(in_dim, sizes):
+    """mpe_actor_forward_f32 against the plain PyTorch fp32 forward + Gumbel-softmax with the same uniforms:
+    <= 1e-5 (different summation order in the three small dot products)."""
+    from marl_amd.maddpg import actor_forward, pack_actor
+    torch.manual_seed(in_dim)
+    B, ld = 5000 + 13, 5376
+    net = mlp_model(in_dim, sum(sizes)).cuda()
+    for m in net:
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.normal_(m.bias, std=0.3)                          # biases are zero at init: make them count
+    obs = (torch.randn(in_dim, ld, device='cuda') * 2)[:, :B].t()          # SoA rows, as env.step returns them
+    u = torch.rand(B, sum(sizes), device='cuda').clamp_(1e-6, 1 - 1e-6)
+    packed = pack_actor(net)
+    got = actor_forward(packed, obs, sizes, u=u)
+    assert got.shape == (B, sum(sizes)) and got.stride(0) == 1 and got.stride(1) == ld
+    with torch.no_grad():
+        noisy = net(obs) - torch.log(-torch.log(u))
+        want = torch.cat([torch.softmax(p, -1) for p in torch.split(noisy, sizes, -1)], -1)
+    assert float((got - want).abs().max()) <= 1e-5
+    own = actor_forward(packed, obs, sizes, seed=7, call_counter=1)       # the kernel's own Philox draw
+    again = actor_forward(packed, obs, sizes, seed=7, call_counter=1)
+    other = actor_forward(packed, obs, sizes, seed=7, call_counter=2)
+    assert torch.equal(own, again) and not torch.equal(own, other)
+    off = 0
+    for s in sizes:
+        assert torch.allclose(own[:, off:off + s].sum(1), torch.ones(B, device='cuda'), atol=1e-5)
+        off += s
+    # the argmax of the relaxed sample follows softmax(logits) (Gumbel-max): compare frequencies on one logit row
+    const_obs = obs[:1].expand(B, in_dim).t().contiguous().t()
+    acts = torch.cat([actor_forward(packed, const_obs, sizes, seed=3, call_counter=c)[:, :sizes[0]] for c in range(1, 21)])
+    with torch.no_grad():
+        p = torch.softmax(net(obs[:1])[0, :sizes[0]], 0)
+    freq = torch.bincount(acts.argmax(1), minlength=sizes[0]).float() / acts.shape[0]
+    assert float((freq - p).abs().max()) < 0.01
