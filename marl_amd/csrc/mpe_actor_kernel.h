@@ -6,8 +6,8 @@
 //
 // for every env in one launch, reading the env kernels' SoA observation rows and writing SoA action rows (the
 // rows env_step reads next), so an acting step moves 4 (in + out) bytes per env and nothing else.  One env per
-// lane: the 64 + 64 hidden activations live in VGPRs, the weights are wave-uniform (layer 1 through the scalar
-// cache as SGPR operands of v_fmac, layers 2 / 3 as LDS broadcast reads), so the inner loops are pure VALU: 2 (in 64 + 64 64 + 64 out) flop
+// lane: the 64 hidden activations live in VGPRs, the weights are wave-uniform and come through the scalar
+// cache (s_load -> SGPR operand of v_fmac), so the inner loops are pure VALU: 2 (in 64 + 64 64 + 64 out) flop
 // per env.  Dense but tiny: at 64 units the whole problem is 11 GFLOP per million envs -- f32 VALU work for
 // ~0.1 ms, not worth an MFMA tiling (fp32 MFMA has the vector rate anyway); f32 because the reference's
 // networks are.  Packed weights (host side, marl_amd/maddpg.py:pack_actor): W1t [in][64], b1 [64], W2t [64][64],
@@ -30,11 +30,7 @@ __global__ __launch_bounds__(256) void actor_forward_kernel(int64_t B, int64_t l
   const bool active = env < B;
   const int64_t ge = active ? env : B - 1;  // tail lanes shadow the last env, their stores are skipped
   const float *W1 = wts, *b1 = W1 + (int64_t)in_dim * H, *W2 = b1 + H;
-  // The 5 200 weights of layers 2 and 3 go through LDS (uniform address = broadcast read).
-  __shared__ float sW[H * H + H + H * O + O];
-  for (int t = threadIdx.x; t < H * H + H + H * O + O; t += 256) sW[t] = W2[t];  // W2, b2, W3, b3 are contiguous
-  __syncthreads();
-  const float *sW2 = sW, *sb2 = sW + H * H, *sW3 = sb2 + H, *sb3 = sW3 + H * O;
+  const float *b2 = W2 + H * H, *W3 = b2 + H, *b3 = W3 + H * O;
   float h1[H], out[O];
 #pragma unroll
   for (int j = 0; j < H; ++j) h1[j] = b1[j];
@@ -47,25 +43,27 @@ __global__ __launch_bounds__(256) void actor_forward_kernel(int64_t B, int64_t l
 #pragma unroll
   for (int j = 0; j < H; ++j) h1[j] = h1[j] > 0.0f ? h1[j] : 0.0f;
 #pragma unroll
-  for (int m = 0; m < O; ++m) out[m] = sb3[m];
+  for (int m = 0; m < O; ++m) out[m] = b3[m];
   // layer 2 in blocks of KB output units (j unrolled: static h1 registers), each block folded into layer 3 at
   // once, so h2 never exists as an array; the block loop stays a real loop, which bounds what the scheduler
-  // may hoist (fully unrolled, it pulls all 5 200 weight reads to the top and spills)
+  // may hoist (fully unrolled, it pulls all 5 200 scalar weight loads to the top and spills 5 000 SGPRs).
+  // Measured, 1 Mi envs, 16 inputs: weights as LDS broadcast reads 424 us (the LDS pipe, shared by the four
+  // SIMDs, is the bound), as scalar loads 213 us.
   constexpr int KB = 8;
 #pragma unroll 1
   for (int kb = 0; kb < H; kb += KB) {
     float acc[KB];
 #pragma unroll
-    for (int kk = 0; kk < KB; ++kk) acc[kk] = sb2[kb + kk];
+    for (int kk = 0; kk < KB; ++kk) acc[kk] = b2[kb + kk];
 #pragma unroll
     for (int j = 0; j < H; ++j)
 #pragma unroll
-      for (int kk = 0; kk < KB; ++kk) acc[kk] = fmaf(sW2[j * H + kb + kk], h1[j], acc[kk]);
+      for (int kk = 0; kk < KB; ++kk) acc[kk] = fmaf(W2[j * H + kb + kk], h1[j], acc[kk]);
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) {
       const float a = acc[kk] > 0.0f ? acc[kk] : 0.0f;
 #pragma unroll
-      for (int m = 0; m < O; ++m) out[m] = fmaf(sW3[(kb + kk) * O + m], a, out[m]);
+      for (int m = 0; m < O; ++m) out[m] = fmaf(W3[(kb + kk) * O + m], a, out[m]);
     }
   }
   // Gumbel noise: caller-supplied uniforms (tests, replaying a recorded draw) or Philox4x32-10 keyed like the

@@ -1,0 +1,36 @@
+"""Time of the fused actor forward kernel on one GPU (run on the GPU box from the repo root):
+    python tools/actor_bench.py
+simple_tag adversary: 16 observation rows in, 5 action rows out, 1 Mi envs; flop = 2 (16 64 + 64 64 + 64 16) per env
+(the kernel always evaluates 16 output columns)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from marl_amd.maddpg import actor_forward, mlp_model, pack_actor  # noqa: E402
+
+
+def main():
+    B, ld = 1 << 20, (1 << 20) + 256
+    for in_dim, sizes in ((16, [5]), (34, [5, 4]), (28, [5, 7])):
+        net = mlp_model(in_dim, sum(sizes)).cuda()
+        packed = pack_actor(net)
+        obs = torch.randn(in_dim, ld, device='cuda')[:, :B].t()
+        for c in range(3):
+            actor_forward(packed, obs, sizes, seed=1, call_counter=c)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for c in range(20):
+            actor_forward(packed, obs, sizes, seed=1, call_counter=c)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 20 * 1e-3
+        flop = 2.0 * B * (in_dim * 64 + 64 * 64 + 64 * 16)
+        print('actor %3d -> 64 -> 64 -> %-7s %d envs: %7.1f us  %5.1f TFLOP/s f32  %5.0f GB/s' %
+              (in_dim, sizes, B, t * 1e6, flop / t / 1e12, 4.0 * B * (in_dim + sum(sizes)) / t / 1e9))
+
+
+if __name__ == '__main__':
+    main()
