@@ -170,8 +170,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, comm
 // simple_crypto in its stock shape (3 fixed speaking agents, 2 landmarks, dim_c 4; simple_crypto.py:24-58):
 // no physics at all -- the step copies the three messages into state.c and scores them against the goal
 // colour.  Pure streaming: 12 action rows in, 12 comm + 20 obs + 3 reward (+ 24 info) rows out.
+#ifndef MPE_CRYPTO_CAP
+#define MPE_CRYPTO_CAP 3  // 2Mi envs f32: 102.4 us uncapped (8) or at 6, 97.4 at 5, 94.1 at 4, 93.3 at 3, 102.0 at 2
+#endif
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(THREADS) void crypto_kernel(const KParams<T> p) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_CRYPTO_CAP))) void crypto_kernel(const KParams<T> p) {
   constexpr int A = 3, C = 4;
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
