@@ -12,8 +12,11 @@
 
 namespace mpe {
 
+#ifndef MPE_WCOMM_CAP
+#define MPE_WCOMM_CAP 2  // 1Mi envs f32: 217.3 us at 4, 208.9 at 3, 203.6 at 2 (320 rows per wavefront)
+#endif
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 3))) void wcomm_kernel(const KParams<T> p) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_WCOMM_CAP))) void wcomm_kernel(const KParams<T> p) {
   constexpr int A = 6, NADV = 4, L = 5, E = A + L, ECOL = A + 1, C = 4;
   constexpr int FOOD0 = A + 1, FOOD1 = A + 3, FOREST0 = A + 3;
   const DevDesc<T> &d = p.d;
