@@ -65,6 +65,8 @@ class ReplayBuffer(object):
 
     def _encode_sample(self, idxes):
         """replay_buffer.py:34-44: (obs [b, od], act [b, ad], rew [b], obs_next [b, od], done [b])."""
+        if self._ring is None:
+            raise IndexError('sample from an empty replay buffer')
         if not torch.is_tensor(idxes):
             idxes = torch.as_tensor(list(idxes), dtype=torch.int64)
         idxes = idxes.to(device=self.device, dtype=torch.int64).contiguous()
