@@ -20,7 +20,10 @@ namespace mpe {
 constexpr int kActorHidden = 64;
 constexpr int kActorMaxOut = 16;
 
-__global__ __launch_bounds__(256) void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0,
+#ifndef MPE_ACTOR_ATTR
+#define MPE_ACTOR_ATTR
+#endif
+__global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0,
                                                             int s1, const float *__restrict__ obs,
                                                             const float *__restrict__ wts, const float *__restrict__ u,
                                                             uint32_t k0, uint32_t k1, uint32_t counter, uint64_t env_id0,
