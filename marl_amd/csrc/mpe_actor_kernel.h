@@ -23,17 +23,18 @@ constexpr int kActorMaxOut = 16;
 #ifndef MPE_ACTOR_ATTR
 #define MPE_ACTOR_ATTR
 #endif
+template <int O>  // output columns evaluated: 8 or 16 (>= s0 + s1); W3t / b3 keep their 16-column packing
 __global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0,
                                                             int s1, const float *__restrict__ obs,
                                                             const float *__restrict__ wts, const float *__restrict__ u,
                                                             uint32_t k0, uint32_t k1, uint32_t counter, uint64_t env_id0,
                                                             float *__restrict__ act) {
-  constexpr int H = kActorHidden, O = kActorMaxOut;
+  constexpr int H = kActorHidden, OP = kActorMaxOut;
   const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = env < B;
   const int64_t ge = active ? env : B - 1;  // tail lanes shadow the last env, their stores are skipped
   const float *W1 = wts, *b1 = W1 + (int64_t)in_dim * H, *W2 = b1 + H;
-  const float *b2 = W2 + H * H, *W3 = b2 + H, *b3 = W3 + H * O;
+  const float *b2 = W2 + H * H, *W3 = b2 + H, *b3 = W3 + H * OP;
   typedef float f2 __attribute__((ext_vector_type(2)));  // packed f32 FMAs (v_pk_fma_f32): two units per instruction
   float h1[H], out[O];
   {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64
       const f2 aa = f2{a, a};
 #pragma unroll
       for (int m = 0; m < O / 2; ++m)
-        out2[m] = __builtin_elementwise_fma(f2{W3[(kb + kk) * O + 2 * m], W3[(kb + kk) * O + 2 * m + 1]}, aa, out2[m]);
+        out2[m] = __builtin_elementwise_fma(f2{W3[(kb + kk) * OP + 2 * m], W3[(kb + kk) * OP + 2 * m + 1]}, aa, out2[m]);
     }
   }
 #pragma unroll

@@ -987,7 +987,8 @@ extern "C" int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, 
   if (misaligned<float>(obs) || misaligned<float>(weights) || misaligned<float>(u) || misaligned<float>(act))
     return MPE_ERR_ALIGN;
   const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-  hipLaunchKernelGGL(actor_forward_kernel, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, in_dim, s0, s1,
+  auto kern = s0 + s1 <= 8 ? actor_forward_kernel<8> : actor_forward_kernel<16>;
+  hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, in_dim, s0, s1,
                      (const float *)obs, (const float *)weights, (const float *)u, (uint32_t)seed,
                      (uint32_t)(seed >> 32), call_counter, env_id0, (float *)act);
   return (int)hipGetLastError();

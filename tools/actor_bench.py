@@ -1,7 +1,7 @@
 """Time of the fused actor forward kernel on one GPU (run on the GPU box from the repo root):
     python tools/actor_bench.py
-simple_tag adversary: 16 observation rows in, 5 action rows out, 1 Mi envs; flop = 2 (16 64 + 64 64 + 64 16) per env
-(the kernel always evaluates 16 output columns)."""
+simple_tag adversary: 16 observation rows in, 5 action rows out, 1 Mi envs; flop = 2 (16 64 + 64 64 + 64 8) per env
+(the kernel evaluates 8 or 16 output columns)."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 20 * 1e-3
-        flop = 2.0 * B * (in_dim * 64 + 64 * 64 + 64 * 16)
+        flop = 2.0 * B * (in_dim * 64 + 64 * 64 + 64 * (8 if sum(sizes) <= 8 else 16))   # columns the kernel evaluates
         print('actor %3d -> 64 -> 64 -> %-7s %d envs: %7.1f us  %5.1f TFLOP/s f32  %5.0f GB/s' %
               (in_dim, sizes, B, t * 1e6, flop / t / 1e12, 4.0 * B * (in_dim + sum(sizes)) / t / 1e9))
 
