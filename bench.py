@@ -145,8 +145,6 @@ def main():
             dist.init_process_group('gloo')
 
     from marl_amd import make_env, _hip
-    if os.environ.get('MPE_FORCE_TILE'):      # tuning aid: run the stock worlds on the generic LDS-tile kernel
-        _hip.lib.mpe_debug_force_tile_kernel(1)
     from marl_amd.distributed import EpisodeStats, shard_range, summarize_stats
 
     scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[args.workload]
@@ -156,6 +154,8 @@ def main():
     has_info = scenario not in ('simple', 'simple_push', 'simple_speaker_listener', 'simple_reference')
     env = make_env(scenario, benchmark=has_info, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
     env.world.env_id0 = env_id0
+    if os.environ.get('MPE_FORCE_TILE'):      # tuning aid: run the stock worlds on the generic LDS-tile kernel
+        env.world.set_flags(_hip.FLAG_FORCE_TILE)
     n = env.n
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
 

@@ -13,9 +13,11 @@
  * Conventions
  *   - Plain C, plain pointers and sizes.  All array arguments (the members of mpe_buffers, `mask`,
  *     the stats vectors) are DEVICE pointers; mpe_scenario_desc and mpe_buffers themselves live in
- *     host memory and are read during the call only.  The library allocates nothing, keeps no global state, never synchronises:
- *     every call only enqueues kernels on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream).  Safe to call concurrently from several threads / processes on different devices.
+ *     host memory and are read during the call only.  The library allocates nothing, keeps no state that changes results (the only
+ *     process-wide data is a per-device record of which kernels already had their dynamic-LDS limit raised),
+ *     never synchronises: every call only enqueues kernels on `stream` (a hipStream_t passed as void*; NULL =
+ *     default stream) of the CURRENT device, which must be the device that owns the buffers.  Safe to call
+ *     concurrently from several threads / processes on different devices.
  *   - Return value: 0 = OK, < 0 = MPE_ERR_* (bad argument; nothing was launched), > 0 = hipError_t
  *     of the failed launch.  Never throws, never aborts.
  *   - Struct-of-arrays device layout, env index fastest ("row" = one scalar for all envs):
@@ -38,8 +40,12 @@
  *     `B` = number of envs processed, `ld` = row stride in elements (ld >= B), so a sub-range of a
  *     larger batch can be processed by offsetting the pointers.
  *   - _f32 / _f64 = arithmetic (and storage) type of the path.  f64 follows the reference's
- *     float64 operation order (max abs deviation from numpy <= 1e-9 per step, in practice ~1e-15);
- *     f32 is the throughput mode (<= 1e-4 relative).
+ *     float64 operation order (max abs deviation from numpy <= 1e-9 per step, in practice ~1e-15 over
+ *     free-running 25-step episodes); f32 is the throughput mode: <= 1e-4 relative PER STEP FROM IDENTICAL
+ *     STATE (hardware rsq / exp / log, ~1 ulp each).  Over a free-running episode f32 trajectories drift apart
+ *     like any chaotic contact dynamics in single precision, and the discrete outputs (rewards of +-10, contact
+ *     counts, visibility masks, the order of equidistant targets) can differ from the float64 reference on an
+ *     env that sits within ~1e-5 of a strict `<` threshold.
  */
 #ifndef MPE_HIP_H
 #define MPE_HIP_H
@@ -50,7 +56,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 5
+#define MPE_ABI_VERSION 6
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -86,6 +92,10 @@ extern "C" {
 #define MPE_ERR_ALIGN (-4)       /* a device pointer is not aligned to its element   */
 #define MPE_ERR_UNSUPPORTED (-5) /* e.g. movable landmarks, non-silent agents        */
 #define MPE_ERR_ARG (-6)         /* any other bad scalar argument                    */
+
+/* mpe_buffers.flags bits (per call; 0 = default behaviour) */
+#define MPE_FLAG_FORCE_TILE 1u   /* run the generic LDS-tile kernel even for a world that has a register-resident
+                                    kernel (tests check both kernels against the same golden vectors; tuning)  */
 
 /*
  * World + scenario constants: what Scenario.make_world() sets up (simple_tag.py:7-36,
@@ -167,6 +177,7 @@ typedef struct mpe_buffers {
   double *stats;     /* [mpe_stats_rows][mpe_stats_width] or NULL */
   const void *cnoise; /* [A][dim_c][ld] standard normals for c_noise (core.py:229): agent.state.c = action.c +
                          c_noise * cnoise for a speaking agent with a c_noise; NULL = no comm noise */
+  uint32_t flags;     /* MPE_FLAG_* bits; unknown bits -> MPE_ERR_ARG */
 } mpe_buffers;
 
 int mpe_abi_version(void);
@@ -334,21 +345,12 @@ int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim,
  * (good,adversary) pairs (simple_tag) or occupied landmarks (simple_spread), [2A+1] number of
  * env-steps.
  * mpe_stats_rows = number of per-workgroup rows mpe_env_step_* accumulates into for this (desc,
- * B, dtype): dtype_bytes is 4 or 8.  mpe_stats_reduce sums the rows in a fixed order (bitwise
+ * B, dtype, flags): dtype_bytes is 4 or 8, flags = the mpe_buffers.flags of the stepping calls.  mpe_stats_reduce sums the rows in a fixed order (bitwise
  * reproducible) into out[width]; that vector is what ranks all-reduce over RCCL.
  */
 int mpe_stats_width(const mpe_scenario_desc *desc);
-int64_t mpe_stats_rows(const mpe_scenario_desc *desc, int64_t B, int dtype_bytes);
+int64_t mpe_stats_rows(const mpe_scenario_desc *desc, int64_t B, int dtype_bytes, uint32_t flags);
 int mpe_stats_reduce(const double *stats, int64_t rows, int width, double *out, void *stream);
-
-/*
- * Test hook (no reference counterpart): on != 0 routes the stock worlds (simple_tag 3+1/2,
- * simple_spread 3/3, simple 1/1, simple_adversary 3/2, simple_push 10/1), which normally run the
- * register-resident kernel, through the generic
- * LDS-tile kernel as well, so both kernels can be checked against the same golden vectors.
- * Process-wide; not for production use.
- */
-void mpe_debug_force_tile_kernel(int on);
 
 #ifdef __cplusplus
 }

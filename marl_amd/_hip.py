@@ -26,7 +26,8 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 5
+ABI_VERSION = 6
+FLAG_FORCE_TILE = 1
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -60,10 +61,11 @@ class ScenarioDesc(C.Structure):
 class Buffers(C.Structure):
     """mpe_buffers (include/mpe_hip.h): device pointers of one batch."""
     _fields_ = [(n, C.c_void_p) for n in ('act', 'noise', 'pos', 'vel', 'comm', 'lforce', 'goal', 'obs', 'rew',
-                                          'info', 'stats', 'cnoise')]
+                                          'info', 'stats', 'cnoise')] + [('flags', C.c_uint32)]
 
-    def __init__(self, **tensors):
+    def __init__(self, flags=0, **tensors):
         super().__init__()
+        self.flags = flags
         self.set(**tensors)
 
     def set(self, **tensors):
@@ -75,7 +77,7 @@ class Buffers(C.Structure):
         return self
 
 
-_BUFFER_NAMES = frozenset(n for n, _ in Buffers._fields_)
+_BUFFER_NAMES = frozenset(n for n, _ in Buffers._fields_ if n != 'flags')
 
 
 class ReplaySeg(C.Structure):
@@ -127,11 +129,9 @@ def _load():
     L.mpe_actor_forward_f32.restype = ci
     L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]
     L.mpe_stats_rows.restype = i64
-    L.mpe_stats_rows.argtypes = [dp, i64, ci]
+    L.mpe_stats_rows.argtypes = [dp, i64, ci, u32]
     L.mpe_stats_reduce.restype = ci
     L.mpe_stats_reduce.argtypes = [vp, i64, ci, vp, vp]
-    L.mpe_debug_force_tile_kernel.restype = None
-    L.mpe_debug_force_tile_kernel.argtypes = [ci]
     L.mpe_desc_sizeof.restype = i64
     L.mpe_desc_sizeof.argtypes = []
     if L.mpe_abi_version() != ABI_VERSION:
@@ -166,3 +166,29 @@ def ptr(t):
 
 def stream_of(device):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device(object):
+    """Makes ``device`` the current HIP device for the duration of a library call.  The C ABI launches on
+    the current device (include/mpe_hip.h); a world / replay buffer / trainer created on ``cuda:1`` while
+    ``cuda:0`` is current would otherwise launch on GPU 0 against GPU 1's memory.  Costs one
+    ``torch.cuda.current_device()`` when the device is already current (the normal one-process-per-GPU case)."""
+    __slots__ = ('idx', 'prev')
+
+    def __init__(self, device):
+        idx = torch.device(device).index
+        self.idx = torch.cuda.current_device() if idx is None else idx
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+            self.prev = None
+        return False

@@ -73,6 +73,7 @@ class AgentState(EntityState):
     def c(self, value):
         r = self._e._world.comm[self._e._index]
         r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], r.shape[0]).t())
+        self._e._world.mark_dirty()      # observations of the speaking scenarios read other.state.c
 
 
 class Action(object):
@@ -278,6 +279,14 @@ class World(object):
         self.mark_dirty()
         return self
 
+    def set_flags(self, flags):
+        """Per-call hints passed in ``mpe_buffers.flags`` (e.g. ``_hip.FLAG_FORCE_TILE``: run the generic LDS-tile
+        kernel for a world that has a register-resident one).  The statistics rows depend on the kernel chosen."""
+        self._buf.flags = int(flags)
+        if self.stats is not None:
+            self.stats = None
+            self.enable_stats()
+
     def mark_dirty(self):
         """Call after writing world.pos / world.vel directly (setters on entity.state do it)."""
         self._tick += 1
@@ -320,9 +329,10 @@ class World(object):
         self._flip_obs()
         d = self.descriptor()
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
-        b = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, obs=self.obs,
-                         comm=self._comm_arg)
-        _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_observe')
+        b = _hip.Buffers(flags=self._buf.flags, pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal,
+                         obs=self.obs, comm=self._comm_arg)
+        with _hip.on_device(self.device):
+            _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_observe')
         self._obs_tick = self._tick
 
     def gather(self, force=False):
@@ -339,13 +349,14 @@ class World(object):
         fn = getattr(_hip.lib, 'mpe_observe_' + _hip.suffix(self.dtype))
         b = self._buf
         b.info = self.info.data_ptr() if self.info.numel() else None
-        _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_observe')
+        with _hip.on_device(self.device):
+            _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_observe')
         self._gather_tick = self._tick
 
     def enable_stats(self):
         """Allocate (or zero) the per-workgroup statistics rows env_step accumulates into."""
         d = self.descriptor()
-        rows = _hip.lib.mpe_stats_rows(d, self.num_envs, 4 if self.dtype == torch.float32 else 8)
+        rows = _hip.lib.mpe_stats_rows(d, self.num_envs, 4 if self.dtype == torch.float32 else 8, self._buf.flags)
         width = _hip.lib.mpe_stats_width(d)
         if self.stats is None or tuple(self.stats.shape) != (rows, width):
             self.stats = torch.zeros(rows, width, dtype=torch.float64, device=self.device)
@@ -357,8 +368,9 @@ class World(object):
         """Deterministic reduction of the statistics rows -> [2A+2] float64 device vector."""
         if out is None:
             out = torch.empty(self.stats.shape[1], dtype=torch.float64, device=self.device)
-        _hip.check(_hip.lib.mpe_stats_reduce(self.stats.data_ptr(), self.stats.shape[0], self.stats.shape[1],
-                                             out.data_ptr(), _hip.stream_of(self.device)), 'mpe_stats_reduce')
+        with _hip.on_device(self.device):
+            _hip.check(_hip.lib.mpe_stats_reduce(self.stats.data_ptr(), self.stats.shape[0], self.stats.shape[1],
+                                                 out.data_ptr(), _hip.stream_of(self.device)), 'mpe_stats_reduce')
         return out
 
     def env_step(self, want_info=True):
@@ -375,7 +387,8 @@ class World(object):
         b.info = self.info.data_ptr() if (want_info and self.info.numel()) else None
         b.stats = _hip.ptr(self.stats)
         self._flip_obs()
-        _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_env_step')
+        with _hip.on_device(self.device):
+            _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_env_step')
         self._tick += 1
         self._obs_tick = self._tick
         if want_info:
@@ -459,5 +472,6 @@ class World(object):
         b = self._buf
         b.act, b.noise = self.act.data_ptr(), nptr
         b.cnoise = self._cnoise_ptr()
-        _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_world_step')
+        with _hip.on_device(self.device):
+            _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_world_step')
         self.mark_dirty()

@@ -23,6 +23,11 @@ constexpr int kActorMaxOut = 16;
 #ifndef MPE_ACTOR_ATTR
 #define MPE_ACTOR_ATTR
 #endif
+// 23 random bits -> a uniform strictly inside (0, 1): (n + 0.5) * 2^-23 is exact in f32 for n < 2^23 (24 bits:
+// n = 2^24 - 1 would round (n + 0.5) up to 2^24 and return exactly 1.0 -> -log(-log(1)) = +inf -> NaN action).
+// min 2^-24, max 1 - 2^-24.
+__device__ __forceinline__ float philox_open01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
 template <int O>  // output columns evaluated: 8 or 16 (>= s0 + s1); W3t / b3 keep their 16-column packing
 __global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0,
                                                             int s1, const float *__restrict__ obs,
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64
       uint32_t w[4];
       philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), counter, 0xC0000000u | (uint32_t)q, k0, k1, w);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g[4 * q + r] = ((float)(w[r] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+      for (int r = 0; r < 4; ++r) g[4 * q + r] = philox_open01(w[r]);
     }
   }
   float mx0 = -INFINITY, mx1 = -INFINITY;

@@ -14,6 +14,7 @@
 // tests/test_gpu_hier.py checks the two bit for bit).
 #pragma once
 #include "mpe_device.h"
+#include "mpe_launch.h"
 
 namespace mpe {
 
@@ -21,9 +22,6 @@ namespace mpe {
 #ifndef MPE_HIER_ATTR
 #define MPE_HIER_ATTR __attribute__((amdgpu_waves_per_eu(1, 3)))
 #endif
-
-constexpr int kHierDimC = 7;
-constexpr int kHierTargets = 3;
 
 // World.step for one env per lane (shared by hier_kernel and moving_kernel): action decode, leader force,
 // pair forces, integration, comm / leader_force write-back; or, when only observing, the leader_force load.

@@ -1,0 +1,43 @@
+// Translation-unit body of the register-kernel launchers for the fork's command-hierarchy worlds (L1F* / S1L*
+// Targets files and the two *_MovingTarget files): included by mpe_hier_f32.hip / mpe_hier_f64.hip with
+// MPE_TU_T = float / double.
+#include <hip/hip_runtime.h>
+
+#include "mpe_launch.h"
+#include "mpe_hier_kernel.h"
+
+namespace mpe {
+
+template <typename T, int A, int L, int NF, bool DO_STEP, bool DO_OBS>
+static int launch_hier(const KParams<T> &p, hipStream_t s) {
+  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+  hipLaunchKernelGGL((hier_kernel<T, A, L, NF, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+template <typename T, bool DO_STEP, bool DO_OBS>
+int launch_hier_id(SmallId sv, const KParams<T> &p, hipStream_t s) {
+  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+  switch (sv) {
+    case HIER_3_3_2: return launch_hier<T, 3, 3, 2, DO_STEP, DO_OBS>(p, s);
+    case HIER_5_3_4: return launch_hier<T, 5, 3, 4, DO_STEP, DO_OBS>(p, s);
+    case HIER_2_10_1: return launch_hier<T, 2, 10, 1, DO_STEP, DO_OBS>(p, s);
+    case HIER_3_10_2: return launch_hier<T, 3, 10, 2, DO_STEP, DO_OBS>(p, s);
+    case HIER_3_10_1: return launch_hier<T, 3, 10, 1, DO_STEP, DO_OBS>(p, s);
+    case HIER_5_3_2: return launch_hier<T, 5, 3, 2, DO_STEP, DO_OBS>(p, s);
+    case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
+    case MOVING_6_4_3:
+      hipLaunchKernelGGL((moving_kernel<T, 6, 4, 3, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    case MOVING_8_4_7:
+      hipLaunchKernelGGL((moving_kernel<T, 8, 4, 7, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    default: return MPE_ERR_UNSUPPORTED;
+  }
+}
+
+template int launch_hier_id<MPE_TU_T, true, false>(SmallId, const KParams<MPE_TU_T> &, hipStream_t);
+template int launch_hier_id<MPE_TU_T, false, true>(SmallId, const KParams<MPE_TU_T> &, hipStream_t);
+template int launch_hier_id<MPE_TU_T, true, true>(SmallId, const KParams<MPE_TU_T> &, hipStream_t);
+
+}  // namespace mpe

@@ -7,12 +7,8 @@
 #include <cstring>
 
 #include "mpe_device.h"
-#include "mpe_comm_kernel.h"
-#include "mpe_wcomm_kernel.h"
+#include "mpe_launch.h"
 #include "mpe_actor_kernel.h"
-#include "mpe_hier_kernel.h"
-#include "mpe_small_kernel.h"
-#include "mpe_tile_kernel.h"
 
 using namespace mpe;
 
@@ -316,27 +312,6 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
 // ------------------------------------------------------------------------------------------------
 // kernel selection
 // ------------------------------------------------------------------------------------------------
-enum SmallId {
-  SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3, SMALL_SIMPLE_1_1, SMALL_ADVERSARY_3_2, SMALL_PUSH_10_1,
-  // command-hierarchy worlds, HIER_<agents>_<targets>_<followers> (mpe_hier_kernel.h)
-  HIER_FIRST,
-  HIER_3_3_2 = HIER_FIRST,  // L1F2_3Targets_*
-  HIER_5_3_4,               // L1F4_3Targets_wide
-  HIER_2_10_1,              // L1F1_10Targets_wide
-  HIER_3_10_2,              // L1F2_10Targets_wide
-  HIER_3_10_1,              // S1L1F1_10Targets_wide
-  HIER_5_3_2,               // S1L2F2_3Targets_*
-  HIER_5_10_2,              // S1L2F2_10Targets_wide(_rewardFixed)
-  HIER_LAST = HIER_5_10_2,
-  // speaking stock scenarios (mpe_comm_kernel.h)
-  COMM_SPEAKER_LISTENER,
-  COMM_REFERENCE,
-  COMM_CRYPTO,
-  WCOMM_4_2_1_2_2,  // simple_world_comm (mpe_wcomm_kernel.h)
-  MOVING_6_4_3,     // L1F4_MovingTarget (agents, followers, dim_c; mpe_hier_kernel.h:moving_kernel)
-  MOVING_8_4_7      // S1L2F4_MovingTarget
-};
-
 // Stock shape of a *_MovingTarget world (moving_kernel header), or SMALL_NONE.
 static SmallId moving_variant(const mpe_scenario_desc *h) {
   const int A = h->n_agents;
@@ -434,134 +409,40 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
   return id;
 }
 
-static bool g_force_tile = false;  // test hook: route the stock worlds through the tile kernel too
-extern "C" void mpe_debug_force_tile_kernel(int on) { g_force_tile = on != 0; }
-
 // Workgroup size of the register kernel for this launch, or 0 = use the tile kernel.
 // simple_push (10 agents) needs ~164 VGPRs in f32 (no 1024-lane workgroups) and > 256 in f64
 // (register kernel would spill: the tile kernel takes it).
-static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, SmallId *out) {
-  SmallId sv = g_force_tile ? SMALL_NONE : small_variant(h);
+static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, uint32_t flags, SmallId *out) {
+  SmallId sv = (flags & MPE_FLAG_FORCE_TILE) ? SMALL_NONE : small_variant(h);
   for (int a = 0; a < h->n_agents; ++a)  // comm noise: the generic kernel only (no stock scenario sets it)
     if (h->c_noise[a] != 0.0 && !h->silent[a]) sv = SMALL_NONE;
   if (out) *out = sv;
   if (sv == SMALL_NONE) return 0;
   if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
-  if (sv >= HIER_FIRST) return kSmallThreads;
-  return small_threads(B, dtype_bytes);
-}
-
-template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
-static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
-  constexpr int TILE = tile_envs<T>();
-  const size_t lds = tile_lds_bytes<T>(h, THREADS);
-  auto kern = kind_is_ragged(h->kind) ? tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, true>
-                                          : tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, false>;
-  if (lds > 64 * 1024) {
-    if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  const dim3 grid((unsigned)tile_grid(p.B, TILE)), block(THREADS);
-  hipLaunchKernelGGL(kern, grid, block, lds, s, p);
-  return (int)hipGetLastError();
-}
-
-template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool DO_STEP, bool DO_OBS>
-static int launch_small(const KParams<T> &p, bool noise, hipStream_t s) {
-  const dim3 grid((unsigned)((p.B + THREADS - 1) / THREADS)), block(THREADS);
-  if (noise)
-    hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-  return (int)hipGetLastError();
-}
-
-template <typename T, int A, int L, int NF, bool DO_STEP, bool DO_OBS>
-static int launch_hier(const KParams<T> &p, hipStream_t s) {
-  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-  hipLaunchKernelGGL((hier_kernel<T, A, L, NF, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-  return (int)hipGetLastError();
-}
-
-template <typename T, int KIND, int C, bool DO_STEP, bool DO_OBS>
-static int launch_comm(const KParams<T> &p, hipStream_t s) {
-  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-  hipLaunchKernelGGL((comm_kernel<T, KIND, C, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-  return (int)hipGetLastError();
-}
-
-template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
-static int launch_small_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) {
-  if constexpr (THREADS == kSmallThreads) {
-    switch (sv) {
-      case HIER_3_3_2: return launch_hier<T, 3, 3, 2, DO_STEP, DO_OBS>(p, s);
-      case HIER_5_3_4: return launch_hier<T, 5, 3, 4, DO_STEP, DO_OBS>(p, s);
-      case HIER_2_10_1: return launch_hier<T, 2, 10, 1, DO_STEP, DO_OBS>(p, s);
-      case HIER_3_10_2: return launch_hier<T, 3, 10, 2, DO_STEP, DO_OBS>(p, s);
-      case HIER_3_10_1: return launch_hier<T, 3, 10, 1, DO_STEP, DO_OBS>(p, s);
-      case HIER_5_3_2: return launch_hier<T, 5, 3, 2, DO_STEP, DO_OBS>(p, s);
-      case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
-      case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
-      case COMM_REFERENCE: return launch_comm<T, MPE_SIMPLE_REFERENCE, 10, DO_STEP, DO_OBS>(p, s);
-      case MOVING_6_4_3:
-      case MOVING_8_4_7: {
-        const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-        if (sv == MOVING_6_4_3)
-          hipLaunchKernelGGL((moving_kernel<T, 6, 4, 3, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-        else
-          hipLaunchKernelGGL((moving_kernel<T, 8, 4, 7, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-        return (int)hipGetLastError();
-      }
-      case WCOMM_4_2_1_2_2: {
-        const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-        hipLaunchKernelGGL((wcomm_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-        return (int)hipGetLastError();
-      }
-      case COMM_CRYPTO: {
-        const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-        hipLaunchKernelGGL((crypto_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-        return (int)hipGetLastError();
-      }
-      default: break;
-    }
-  }
-  switch (sv) {
-    case SMALL_TAG_3_1_2: return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, THREADS, DO_STEP, DO_OBS>(p, noise, s);
-    case SMALL_SPREAD_3_3: return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, THREADS, DO_STEP, DO_OBS>(p, noise, s);
-    case SMALL_SIMPLE_1_1: return launch_small<T, MPE_SIMPLE, 1, 1, 0, THREADS, DO_STEP, DO_OBS>(p, noise, s);
-    case SMALL_ADVERSARY_3_2: return launch_small<T, MPE_SIMPLE_ADVERSARY, 3, 2, 1, THREADS, DO_STEP, DO_OBS>(p, noise, s);
-    case SMALL_PUSH_10_1:
-      if constexpr (sizeof(T) == 4 && THREADS == kSmallThreads)
-        return launch_small<T, MPE_SIMPLE_PUSH, 10, 1, 9, THREADS, DO_STEP, DO_OBS>(p, noise, s);
-      return MPE_ERR_UNSUPPORTED;
-    default: return MPE_ERR_UNSUPPORTED;
-  }
+  return kSmallThreads;
 }
 
 template <typename T, bool DO_STEP, bool DO_OBS>
-static int launch(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
+static int launch(const mpe_scenario_desc *h, const KParams<T> &p, uint32_t flags, hipStream_t s) {
   SmallId sv;
-  const int threads = small_launch_threads(h, p.B, (int)sizeof(T), &sv);
+  const int threads = small_launch_threads(h, p.B, (int)sizeof(T), flags, &sv);
   if (threads != 0) {
+    if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, p, s);
     bool noise = false;
     if (DO_STEP && p.noise != nullptr)
       for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
-    return launch_small_id<T, kSmallThreads, DO_STEP, DO_OBS>(sv, p, noise, s);
+    return launch_stock_id<T, DO_STEP, DO_OBS>(sv, p, noise, s);
   }
-  // Large worlds are LDS-limited to 1-2 workgroups per CU: give those workgroups more wavefronts so
-  // the compute-heavy pair phase and the store-heavy observation phase still find work to overlap.
-  const int E = h->n_agents + h->n_landmarks;
-  if (E > 32) return launch_tile<T, 512, DO_STEP, DO_OBS>(h, p, s);
-  return launch_tile<T, 256, DO_STEP, DO_OBS>(h, p, s);
+  return launch_tile_world<T, DO_STEP, DO_OBS>(h, p, s);
 }
 
-extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dtype_bytes) {
+extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, uint32_t flags) {
   int rc = mpe_desc_check(h);
   if (rc) return rc;
   if (B < 1) return MPE_ERR_BATCH;
   if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
-  const int threads = small_launch_threads(h, B, dtype_bytes, nullptr);
+  if (flags & ~(uint32_t)MPE_FLAG_FORCE_TILE) return MPE_ERR_ARG;
+  const int threads = small_launch_threads(h, B, dtype_bytes, flags, nullptr);
   if (threads != 0) return (B + threads - 1) / threads;
   return tile_grid(B, dtype_bytes == 4 ? tile_envs<float>() : tile_envs<double>());
 }
@@ -584,6 +465,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
   if (!b || !b->pos || !b->vel) return MPE_ERR_NULL;
+  if (b->flags & ~(uint32_t)MPE_FLAG_FORCE_TILE) return MPE_ERR_ARG;
   if (do_step && !b->act) return MPE_ERR_NULL;
   const bool lf = has_lforce(h);
   if (lf && !b->lforce) return MPE_ERR_NULL;
@@ -621,7 +503,7 @@ static int world_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, co
   KParams<T> p{};
   int rc = bind_buffers<T>(h, B, ld, b, true, false, p);
   if (rc) return rc;
-  return launch<T, true, false>(h, p, (hipStream_t)stream);
+  return launch<T, true, false>(h, p, b->flags, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -630,7 +512,7 @@ static int observe_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   int rc = bind_buffers<T>(h, B, ld, b, false, true, p);
   if (rc) return rc;
   if (!p.obs && !p.rew && !p.info) return MPE_ERR_NULL;
-  return launch<T, false, true>(h, p, (hipStream_t)stream);
+  return launch<T, false, true>(h, p, b->flags, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -638,7 +520,7 @@ static int env_step_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, cons
   KParams<T> p{};
   int rc = bind_buffers<T>(h, B, ld, b, true, true, p);
   if (rc) return rc;
-  return launch<T, true, true>(h, p, (hipStream_t)stream);
+  return launch<T, true, true>(h, p, b->flags, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,60 @@
+// Kernel selection ids, launch geometry and the launcher templates shared by the translation units of
+// libmpe_hip.so.  The kernels are instantiated in their own .hip files (mpe_tile_f32.hip, mpe_tile_f64.hip,
+// mpe_small_f32.hip, mpe_small_f64.hip) so that the library builds in parallel; mpe_hip.hip holds the C ABI,
+// the validation and the selection logic and only calls the launchers declared here.
+#pragma once
+#include "mpe_device.h"
+
+namespace mpe {
+
+enum SmallId {
+  SMALL_NONE = 0, SMALL_TAG_3_1_2, SMALL_SPREAD_3_3, SMALL_SIMPLE_1_1, SMALL_ADVERSARY_3_2, SMALL_PUSH_10_1,
+  // command-hierarchy worlds, HIER_<agents>_<targets>_<followers> (mpe_hier_kernel.h)
+  HIER_FIRST,
+  HIER_3_3_2 = HIER_FIRST,  // L1F2_3Targets_*
+  HIER_5_3_4,               // L1F4_3Targets_wide
+  HIER_2_10_1,              // L1F1_10Targets_wide
+  HIER_3_10_2,              // L1F2_10Targets_wide
+  HIER_3_10_1,              // S1L1F1_10Targets_wide
+  HIER_5_3_2,               // S1L2F2_3Targets_*
+  HIER_5_10_2,              // S1L2F2_10Targets_wide(_rewardFixed)
+  HIER_LAST = HIER_5_10_2,
+  // speaking stock scenarios (mpe_comm_kernel.h)
+  COMM_SPEAKER_LISTENER,
+  COMM_REFERENCE,
+  COMM_CRYPTO,
+  WCOMM_4_2_1_2_2,  // simple_world_comm (mpe_wcomm_kernel.h)
+  MOVING_6_4_3,     // L1F4_MovingTarget (agents, followers, dim_c; mpe_hier_kernel.h:moving_kernel)
+  MOVING_8_4_7      // S1L2F4_MovingTarget
+};
+
+constexpr int kSmallThreads = 256;  // workgroup of the one-env-per-lane register kernels
+constexpr int kHierDimC = 7;        // stock shape of the L1F* / S1L* Targets files
+constexpr int kHierTargets = 3;
+
+// ---- LDS-tile kernel geometry (mpe_tile_kernel.h) ------------------------------------------------------------
+#ifndef MPE_TILE_F32
+#define MPE_TILE_F32 64
+#endif
+template <typename T>
+constexpr int tile_envs() { return sizeof(T) == 4 ? MPE_TILE_F32 : 32; }
+
+inline int64_t tile_grid(int64_t B, int tile) {
+  const int64_t nt = (B + tile - 1) / tile;
+  return nt < 16384 ? nt : 16384;
+}
+
+// Runs the generic LDS-tile kernel (any A <= 64, E <= 128) for this world.  Defined in mpe_tile_f32.hip /
+// mpe_tile_f64.hip for (DO_STEP, DO_OBS) = (1,0), (0,1), (1,1).
+template <typename T, bool DO_STEP, bool DO_OBS>
+int launch_tile_world(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s);
+
+// Run the register kernel `sv` (one env per lane, stock shapes): the stock scenarios' kernels are defined in
+// mpe_small_f32.hip / mpe_small_f64.hip, the command-hierarchy ones in mpe_hier_f32.hip / mpe_hier_f64.hip.
+template <typename T, bool DO_STEP, bool DO_OBS>
+int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s);
+template <typename T, bool DO_STEP, bool DO_OBS>
+int launch_hier_id(SmallId sv, const KParams<T> &p, hipStream_t s);
+inline bool small_id_is_hier(SmallId sv) { return (sv >= HIER_FIRST && sv <= HIER_LAST) || sv == MOVING_6_4_3 || sv == MOVING_8_4_7; }
+
+}  // namespace mpe

@@ -20,6 +20,7 @@
 // is re-read every step, can stay in L2 / Infinity Cache.
 #pragma once
 #include "mpe_device.h"
+#include "mpe_launch.h"
 
 namespace mpe {
 
@@ -34,8 +35,6 @@ constexpr int small_wave_cap(int kind) { return kind == MPE_SIMPLE ? 8 : 3; }
 #ifndef MPE_SMALL_ATTR
 #define MPE_SMALL_ATTR __attribute__((amdgpu_waves_per_eu(1, small_wave_cap(KIND))))
 #endif
-constexpr int kSmallThreads = 256;
-inline int small_threads(int64_t, int) { return kSmallThreads; }
 
 template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
 __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KParams<T> p) {

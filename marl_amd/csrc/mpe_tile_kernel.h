@@ -21,6 +21,7 @@
 // order, it needs no cross-lane traffic at all, and the lanes are already full with envs.
 #pragma once
 #include "mpe_device.h"
+#include "mpe_launch.h"
 
 namespace mpe {
 
@@ -831,12 +832,6 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   }
 }
 
-#ifndef MPE_TILE_F32
-#define MPE_TILE_F32 64
-#endif
-template <typename T>
-constexpr int tile_envs() { return sizeof(T) == 4 ? MPE_TILE_F32 : 32; }
-
 // LDS bytes: pos rows + max(vel rows, aux rows); aux = (n_adv + NCH) int rows (tag) or L rows of T (spread).
 template <typename T>
 inline size_t tile_lds_bytes(const mpe_scenario_desc *h, int threads) {
@@ -851,11 +846,6 @@ inline size_t tile_lds_bytes(const mpe_scenario_desc *h, int threads) {
   for (int a = 0; a < h->n_agents; ++a)
     if (h->forced_id[a] >= 0) lfb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
   return (size_t)(2 * E) * TILE * sizeof(T) + lfb + velb;
-}
-
-inline int64_t tile_grid(int64_t B, int tile) {
-  const int64_t nt = (B + tile - 1) / tile;
-  return nt < 16384 ? nt : 16384;
 }
 
 }  // namespace mpe

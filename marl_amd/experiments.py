@@ -21,8 +21,9 @@ def target_move(env):
     d = w.descriptor()
     count = torch.empty(w.num_envs, dtype=torch.int32, device=w.device)
     fn = getattr(_hip.lib, 'mpe_target_move_' + _hip.suffix(w.dtype))
-    _hip.check(fn(d, w.num_envs, w.ld, w.seed, w.move_counter, w.env_id0, _hip.Buffers(pos=w.pos),
-                  count.data_ptr(), _hip.stream_of(w.device)), 'mpe_target_move')
+    with _hip.on_device(w.device):
+        _hip.check(fn(d, w.num_envs, w.ld, w.seed, w.move_counter, w.env_id0, _hip.Buffers(pos=w.pos),
+                      count.data_ptr(), _hip.stream_of(w.device)), 'mpe_target_move')
     w.move_counter += 1
     w.mark_dirty()
     return count
@@ -32,9 +33,10 @@ def _scripted(agent, world, mode, target):
     act = world.rows(5)                      # [5, B] view with the world's row stride
     point = world.rows(2)
     fn = getattr(_hip.lib, 'mpe_scripted_action_' + _hip.suffix(world.dtype))
-    _hip.check(fn(world.descriptor(), world.num_envs, world.ld, agent._index, mode, target, PREY_ACTION_CAP,
-                  world.pos.data_ptr(), act.data_ptr(), point.data_ptr(), _hip.stream_of(world.device)),
-               'mpe_scripted_action')
+    with _hip.on_device(world.device):
+        _hip.check(fn(world.descriptor(), world.num_envs, world.ld, agent._index, mode, target, PREY_ACTION_CAP,
+                      world.pos.data_ptr(), act.data_ptr(), point.data_ptr(), _hip.stream_of(world.device)),
+                   'mpe_scripted_action')
     return act.t(), point.t()
 
 

@@ -74,7 +74,8 @@ def pack_actor(net):
 def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0):
     """One launch of libmpe_hip.so:mpe_actor_forward_f32.  ``obs``: ``[B, in_dim]`` view of SoA rows (strides
     (1, ld)), as env.step returns it.  Returns the action as the same kind of view (``[B, sum(sizes)]`` over SoA rows
-    with the same ld), which env.step adopts without a copy.  ``u``: optional ``[B, sum(sizes)]`` uniforms (same
+    with the same ld); env.step copies it row-wise into the env's action buffer (a per-agent list is never adopted in
+    place: only a whole [act_total, B] buffer with the world's stride is).  ``u``: optional ``[B, sum(sizes)]`` uniforms (same
     layout) instead of the kernel's own Philox draw."""
     from . import _hip
     B, in_dim = obs.shape
@@ -86,9 +87,10 @@ def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0)
         uu[:, :B] = u.t()
         u = uu[:, :B].t()
     s0, s1 = sizes[0], (sizes[1] if len(sizes) > 1 else 0)
-    _hip.check(_hip.lib.mpe_actor_forward_f32(B, ld, ld, in_dim, s0, s1, obs.data_ptr(), packed.data_ptr(),
-                                              None if u is None else u.data_ptr(), seed, call_counter, env_id0,
-                                              act.data_ptr(), _hip.stream_of(obs.device)), 'mpe_actor_forward')
+    with _hip.on_device(obs.device):
+        _hip.check(_hip.lib.mpe_actor_forward_f32(B, ld, ld, in_dim, s0, s1, obs.data_ptr(), packed.data_ptr(),
+                                                  None if u is None else u.data_ptr(), seed, call_counter, env_id0,
+                                                  act.data_ptr(), _hip.stream_of(obs.device)), 'mpe_actor_forward')
     return act[:, :B].t()
 
 
@@ -112,7 +114,10 @@ class MADDPGAgentTrainer(object):
     appends one step of all B envs to this agent's replay ring."""
 
     def __init__(self, name, obs_shape_n, act_space_n, agent_index, args, local_q_func=False, model=mlp_model,
-                 device='cuda', dtype=torch.float32, replay_size=1e6):
+                 device='cuda', dtype=torch.float32, replay_size=1e6, seed=0, env_id0=0):
+        """``seed``: the run's seed (keys the exploration noise of the fused actor kernel together with the agent
+        index); ``env_id0``: global id of this process's env 0 (``world.env_id0`` of an env-sharded multi-GPU run), so
+        that the noise of env ``i`` does not depend on how the batch is sharded -- like the reset RNG."""
         self.name = name
         self.n = len(obs_shape_n)
         self.agent_index = agent_index
@@ -137,7 +142,8 @@ class MADDPGAgentTrainer(object):
         self.replay_sample_index = None
         self._packed = None            # packed actor weights for the fused kernel; dropped by every update
         self._act_calls = 0
-        self.seed = 0x5EED0000 + agent_index
+        self.seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x5EED0000 + agent_index) & 0xFFFFFFFFFFFFFFFF
+        self.env_id0 = int(env_id0)
 
     # -- acting ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -154,7 +160,8 @@ class MADDPGAgentTrainer(object):
                 self._packed = pack_actor(self.p)
             if self._packed is not None:
                 self._act_calls += 1
-                return actor_forward(self._packed, obs, sizes, seed=self.seed, call_counter=self._act_calls)
+                return actor_forward(self._packed, obs, sizes, seed=self.seed, call_counter=self._act_calls,
+                                     env_id0=self.env_id0)
         return soft_sample(self.p(obs), sizes)
 
     @torch.no_grad()

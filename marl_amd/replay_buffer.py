@@ -23,6 +23,7 @@ class ReplayBuffer(object):
         if self.device.type != 'cuda':
             raise RuntimeError('marl_amd.ReplayBuffer lives in GPU memory (no CPU fallback)')
         self.dtype = dtype
+        self.check_index = True    # validate sample indices like the reference's list indexing (one host sync)
         self._ring = None          # [capacity, width], allocated by the first add()
         self._dims = None          # (obs_dim, act_dim)
 
@@ -57,8 +58,9 @@ class ReplayBuffer(object):
             raise ValueError('transition shape changed: %s' % ((segs[0].rows, segs[1].rows),))
         arr = (_hip.ReplaySeg * 5)(*segs)
         fn = getattr(_hip.lib, 'mpe_replay_add_' + _hip.suffix(self.dtype))
-        _hip.check(fn(self._maxsize, self._next_idx, n, width, 5, arr, self._ring.data_ptr(),
-                      _hip.stream_of(self.device)), 'mpe_replay_add')
+        with _hip.on_device(self.device):
+            _hip.check(fn(self._maxsize, self._next_idx, n, width, 5, arr, self._ring.data_ptr(),
+                          _hip.stream_of(self.device)), 'mpe_replay_add')
         self._keep = keep          # sources stay alive until the stream has consumed them
         self._next_idx = (self._next_idx + n) % self._maxsize
         self._len = min(self._len + n, self._maxsize)
@@ -71,11 +73,18 @@ class ReplayBuffer(object):
             idxes = torch.as_tensor(list(idxes), dtype=torch.int64)
         idxes = idxes.to(device=self.device, dtype=torch.int64).contiguous()
         b = idxes.numel()
+        if self.check_index and b:
+            # the reference indexes a Python list of len(self) transitions: anything outside raises IndexError
+            # (negative indices count from the end there; they are not used by any caller and rejected here)
+            lo, hi = torch.aminmax(idxes)
+            if int(lo) < 0 or int(hi) >= self._len:
+                raise IndexError('replay index out of range [0, %d): min %d, max %d' % (self._len, int(lo), int(hi)))
         od, ad = self._dims
         out = torch.empty(b, self._ring.shape[1], dtype=self.dtype, device=self.device)
         fn = getattr(_hip.lib, 'mpe_replay_gather_' + _hip.suffix(self.dtype))
-        _hip.check(fn(self._maxsize, out.shape[1], idxes.data_ptr(), b, self._ring.data_ptr(), out.data_ptr(),
-                      _hip.stream_of(self.device)), 'mpe_replay_gather')
+        with _hip.on_device(self.device):
+            _hip.check(fn(self._maxsize, out.shape[1], idxes.data_ptr(), b, self._ring.data_ptr(), out.data_ptr(),
+                          _hip.stream_of(self.device)), 'mpe_replay_gather')
         return (out[:, :od], out[:, od:od + ad], out[:, od + ad], out[:, od + ad + 1:2 * od + ad + 1],
                 out[:, 2 * od + ad + 1])
 
@@ -85,6 +94,8 @@ class ReplayBuffer(object):
 
     def make_latest_index(self, batch_size):
         """replay_buffer.py:49-52: the latest ``batch_size`` slots, shuffled."""
+        if batch_size > self._len:
+            raise IndexError('make_latest_index(%d) with only %d transitions stored' % (batch_size, self._len))
         idx = (self._next_idx - 1 - torch.arange(batch_size, device=self.device, dtype=torch.int64)) % self._maxsize
         return idx[torch.randperm(batch_size, device=self.device)]
 

@@ -39,8 +39,9 @@ class HipScenario(BaseScenario):
         fn = getattr(_hip.lib, 'mpe_reset_' + _hip.suffix(world.dtype))
         b = _hip.Buffers(pos=world.pos, vel=world.vel, comm=world.comm if world.comm.numel() else None,
                          goal=world.goal if world.hip_kind in _hip.GOAL_KINDS else None)
-        _hip.check(fn(d, world.num_envs, world.ld, world.seed, world.episode, world.env_id0,
-                      _hip.ptr(mask), b, _hip.stream_of(world.device)), 'mpe_reset')
+        with _hip.on_device(world.device):
+            _hip.check(fn(d, world.num_envs, world.ld, world.seed, world.episode, world.env_id0,
+                          _hip.ptr(mask), b, _hip.stream_of(world.device)), 'mpe_reset')
         world.episode += 1
         world.mark_dirty()
 

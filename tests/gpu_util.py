@@ -12,6 +12,23 @@ lib = _hip.lib
 from tests.gpu_util_host import desc_from_spec  # noqa: E402,F401
 
 
+class _Mode:
+    force_tile = 0          # MPE_FLAG_FORCE_TILE on every HipSim call (set by the tests' force_tile fixtures)
+
+
+def set_force_tile(on):
+    """Per-call flag (mpe_buffers.flags) that routes the stock worlds through the generic LDS-tile kernel."""
+    _Mode.force_tile = int(bool(on))
+
+
+def call_flags():
+    return _hip.FLAG_FORCE_TILE if _Mode.force_tile else 0
+
+
+def stats_rows(desc, B, dtype_bytes):
+    return lib.mpe_stats_rows(desc, B, dtype_bytes, call_flags())
+
+
 def dev(x, dtype):
     return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
 
@@ -49,7 +66,7 @@ class HipSim:
 
     def buffers(self, **kw):
         """mpe_buffers with the state members set, plus the given tensors."""
-        return _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
+        return _hip.Buffers(flags=call_flags(), pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
 
     def env_step(self, act, noise=None, stats=None, want_info=True, comm=None, cnoise=None):
         self._act, self._noise, self._cnoise = act, noise, cnoise   # keep alive until the stream has consumed them

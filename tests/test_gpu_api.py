@@ -475,3 +475,34 @@ def test_previous_observations_survive_the_next_step():
         o2, _, _, _ = env.step(act)
         assert o1[0].data_ptr() == o2[0].data_ptr()
 
+
+
+def test_comm_state_setter_invalidates_cached_observations():
+    """agent.state.c = ... must mark the world dirty like the p_pos / p_vel setters: scenarios that observe
+    other.state.c (simple_reference.py:79-89) would otherwise return the gather cached before the write."""
+    from marl_amd import make_env
+    env = make_env('simple_reference', num_envs=64, dtype=torch.float64, seed=3)
+    env.reset()
+    sc_obs = env.observation_callback
+    w = env.world
+    a0, a1 = w.agents
+    before = sc_obs(a1, w).clone()
+    a0.state.c = np.arange(1, w.dim_c + 1, dtype=np.float64)
+    after = sc_obs(a1, w)                                    # agent 1 sees agent 0's message in its last dim_c entries
+    assert torch.equal(after[:, -w.dim_c:], torch.arange(1, w.dim_c + 1, dtype=torch.float64, device='cuda').expand(64, -1))
+    assert torch.equal(after[:, :-w.dim_c], before[:, :-w.dim_c])
+
+
+def test_library_calls_run_on_the_worlds_device():
+    """_hip.on_device: a no-op when the world's device is current, otherwise it switches for the call and back.
+    (One GPU on the test box: the switch itself is exercised with the same index.)"""
+    from marl_amd import _hip, make_env
+    cur = torch.cuda.current_device()
+    with _hip.on_device(torch.device('cuda', cur)) as g:
+        assert g.prev is None and torch.cuda.current_device() == cur
+    with _hip.on_device('cuda'):
+        assert torch.cuda.current_device() == cur
+    env = make_env('simple_tag', num_envs=32, device='cuda:%d' % cur, dtype=torch.float32)
+    env.reset()
+    env.step(torch.rand(32, 4, 5, device='cuda'))
+    assert torch.cuda.current_device() == cur

@@ -14,7 +14,7 @@ from oracle import mpe_oracle as O
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.gpu_util import HipSim, dev, golden_soa, lib
+    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_force_tile, stats_rows
 
 CASES = [('g10_simple_speaker_listener', O.speaker_listener_spec), ('g11_simple_reference', O.simple_reference_spec),
          ('g12_simple_crypto', O.simple_crypto_spec)]
@@ -49,9 +49,9 @@ def _maxerr(got, want):
 def force_tile(request):
     """The stock shapes run the register kernel (mpe_comm_kernel.h); the hook routes them through the
     generic LDS-tile kernel too."""
-    lib.mpe_debug_force_tile_kernel(request.param)
+    set_force_tile(request.param)
     yield request.param
-    lib.mpe_debug_force_tile_kernel(0)
+    set_force_tile(0)
 
 
 @SPECS
@@ -66,7 +66,7 @@ def test_register_and_tile_kernels_bit_identical(mk):
     for dtype in (torch.float64, torch.float32):
         res = []
         for ft in (0, 1):
-            lib.mpe_debug_force_tile_kernel(ft)
+            set_force_tile(ft)
             sim = HipSim(spec, B, dtype)
             sim.set_state(pos, vel, goal)
             sim.comm[:] = 0.25
@@ -75,7 +75,7 @@ def test_register_and_tile_kernels_bit_identical(mk):
             for t in range(4):
                 sim.env_step(dev(acts[t], dtype), comm=sim.comm)
             res.append(out + list(sim.host()) + [sim.comm.cpu().numpy()])
-        lib.mpe_debug_force_tile_kernel(0)
+        set_force_tile(0)
         for x, y in zip(*res):
             assert np.array_equal(x, y, equal_nan=True)
 
@@ -123,7 +123,7 @@ def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtyp
     a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
     a.set_state(pos, vel, goal)
     b.set_state(pos, vel, goal)
-    rows, width = lib.mpe_stats_rows(a.desc, B, 8 if dtype == torch.float64 else 4), lib.mpe_stats_width(a.desc)
+    rows, width = stats_rows(a.desc, B, 8 if dtype == torch.float64 else 4), lib.mpe_stats_width(a.desc)
     stats = torch.zeros(rows, width, dtype=torch.float64, device='cuda')
     bo = O.BatchedOracle(spec)
     want_sum = np.zeros(spec.n_agents)

@@ -19,7 +19,7 @@ from oracle import mpe_oracle as O
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.gpu_util import HipSim, dev, golden_soa, lib
+    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_force_tile, stats_rows
 
 F64_TOL = 1e-9
 BASES = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
@@ -43,9 +43,9 @@ def _load(golden_dir, name):
 def force_tile(request):
     """The stock shapes run the register kernel (mpe_hier_kernel.h) by default; the hook routes them
     through the generic LDS-tile kernel too."""
-    lib.mpe_debug_force_tile_kernel(request.param)
+    set_force_tile(request.param)
     yield request.param
-    lib.mpe_debug_force_tile_kernel(0)
+    set_force_tile(0)
 
 
 def _maxerr(got, want):
@@ -218,7 +218,7 @@ def test_register_and_tile_kernels_bit_identical(golden_dir, base):
         _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 4, 21)
         res = []
         for ft in (0, 1):
-            lib.mpe_debug_force_tile_kernel(ft)
+            set_force_tile(ft)
             sim = HipSim(spec, B, dtype)
             sim.set_state(pos, vel, lforce=lf0)
             comm = torch.zeros(spec.n_agents, spec.dim_c, B, dtype=dtype, device='cuda')
@@ -227,7 +227,7 @@ def test_register_and_tile_kernels_bit_identical(golden_dir, base):
             for t in range(4):
                 sim.env_step(dev(acts[t], dtype), comm=comm)
             res.append(out + list(sim.host()) + [sim.lforce.cpu().numpy(), comm.cpu().numpy()])
-        lib.mpe_debug_force_tile_kernel(0)
+        set_force_tile(0)
         for x, y in zip(*res):
             assert np.array_equal(x, y, equal_nan=True)
 
@@ -241,7 +241,7 @@ def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, base, force_tile
     sim = HipSim(spec, B, torch.float64)
     sim.set_state(pos, vel, lforce=lf0)
     A = spec.n_agents
-    rows, width = lib.mpe_stats_rows(sim.desc, B, 8), lib.mpe_stats_width(sim.desc)
+    rows, width = stats_rows(sim.desc, B, 8), lib.mpe_stats_width(sim.desc)
     stats = torch.zeros(rows, width, dtype=torch.float64, device='cuda')
     want = np.zeros(width)
     bo = O.BatchedOracle(spec)

@@ -18,7 +18,7 @@ from oracle import mpe_oracle as O
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.gpu_util import HipSim, dev, golden_soa, lib
+    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_force_tile, stats_rows
 
 F64_TOL = 1e-9
 
@@ -45,9 +45,9 @@ def _load(golden_dir, name):
 
 @pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
 def force_tile(request):
-    lib.mpe_debug_force_tile_kernel(request.param)
+    set_force_tile(request.param)
     yield request.param
-    lib.mpe_debug_force_tile_kernel(0)
+    set_force_tile(0)
 
 
 def _maxerr(got, want):
@@ -167,13 +167,13 @@ def test_small_and_tile_kernels_bit_identical(mk):
         act = dev(rng.rand(spec.n_agents, 5, B), dtype)
         res = []
         for ft in (0, 1):
-            lib.mpe_debug_force_tile_kernel(ft)
+            set_force_tile(ft)
             sim = HipSim(spec, B, dtype)
             sim.set_state(pos, vel, np.arange(B) % max(spec.n_landmarks, 1))
             for _ in range(5):
                 sim.env_step(act)
             res.append(sim.host())
-        lib.mpe_debug_force_tile_kernel(0)
+        set_force_tile(0)
         for x, y in zip(*res):
             assert np.array_equal(x, y, equal_nan=True)
 
@@ -328,7 +328,7 @@ def test_episode_stats_rows_and_reduce(mk, force_tile):
     rng = np.random.RandomState(11)
     sim = HipSim(spec, B, torch.float32)
     sim.set_state(rng.uniform(-0.3, 0.3, (spec.n_entities, 2, B)), np.zeros((A, 2, B)))
-    rows = lib.mpe_stats_rows(sim.desc, B, 4)
+    rows = stats_rows(sim.desc, B, 4)
     W = lib.mpe_stats_width(sim.desc)
     assert W == 2 * A + 2 and rows >= 1
     stats = torch.zeros(rows, W, dtype=torch.float64, device='cuda')
@@ -401,7 +401,7 @@ def test_episode_stats_of_the_goal_scenarios(mk, force_tile):
     sim = HipSim(spec, B, torch.float32)
     sim.set_state(rng.uniform(-0.5, 0.5, (spec.n_entities, 2, B)), np.zeros((A, 2, B)),
                   rng.randint(0, spec.n_landmarks, B))
-    rows, W = lib.mpe_stats_rows(sim.desc, B, 4), lib.mpe_stats_width(sim.desc)
+    rows, W = stats_rows(sim.desc, B, 4), lib.mpe_stats_width(sim.desc)
     stats = torch.zeros(rows, W, dtype=torch.float64, device='cuda')
     want = torch.zeros(A, dtype=torch.float64, device='cuda')
     for t in range(4):

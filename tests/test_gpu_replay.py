@@ -83,3 +83,21 @@ def test_training_loop_shape_with_the_env():
     index = bufs[0].make_index(256)
     for i in range(env.n):
         _check(bufs[i], oracles[i], _np(index))
+
+
+def test_out_of_range_indices_raise_like_the_reference():
+    """replay_buffer.py:34-44 indexes a Python list of len(self) transitions: an index beyond it raises IndexError
+    (the gather kernel wraps indices so that it cannot fault; the Python class must not hand out
+    never-written rows silently)."""
+    from marl_amd.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(100, dtype=torch.float32)
+    z = lambda *s: torch.rand(*s, device='cuda')
+    rb.add(z(10, 3), z(10, 2), z(10), z(10, 3), z(10))
+    rb.sample_index(torch.tensor([0, 9], device='cuda'))
+    for bad in ([10], [0, 99], [-1], [100], [1 << 40]):
+        with pytest.raises(IndexError):
+            rb.sample_index(torch.tensor(bad, device='cuda'))
+    with pytest.raises(IndexError):
+        rb.make_latest_index(11)
+    rb.check_index = False                                                # opt out: no host sync, kernel wraps
+    rb.sample_index(torch.tensor([150], device='cuda'))

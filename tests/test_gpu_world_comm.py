@@ -14,7 +14,7 @@ from oracle import mpe_oracle as O
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.gpu_util import HipSim, dev, golden_soa, lib
+    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_force_tile, stats_rows
 
 CASES = ['g13_simple_world_comm', 'g13_simple_world_comm_dense']
 
@@ -29,9 +29,9 @@ def _maxerr(got, want):
 
 @pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
 def force_tile(request):
-    lib.mpe_debug_force_tile_kernel(request.param)
+    set_force_tile(request.param)
     yield request.param
-    lib.mpe_debug_force_tile_kernel(0)
+    set_force_tile(0)
 
 
 def _random_state(spec, B, seed, spread=0.6):
@@ -111,7 +111,7 @@ def test_split_entry_points_equal_fused_and_random_batch_matches_oracle(mk, dtyp
     a, b = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
     a.set_state(pos, vel)
     b.set_state(pos, vel)
-    rows, width = lib.mpe_stats_rows(a.desc, B, 8 if dtype == torch.float64 else 4), lib.mpe_stats_width(a.desc)
+    rows, width = stats_rows(a.desc, B, 8 if dtype == torch.float64 else 4), lib.mpe_stats_width(a.desc)
     stats = torch.zeros(rows, width, dtype=torch.float64, device='cuda')
     bo = O.BatchedOracle(spec)
     want = np.zeros(width)
@@ -155,7 +155,7 @@ def test_register_and_tile_kernels_bit_identical():
     for dtype in (torch.float64, torch.float32):
         res = []
         for ft in (0, 1):
-            lib.mpe_debug_force_tile_kernel(ft)
+            set_force_tile(ft)
             sim = HipSim(spec, B, dtype)
             sim.set_state(pos, vel)
             sim.comm[:] = 0.25
@@ -164,7 +164,7 @@ def test_register_and_tile_kernels_bit_identical():
             for t in range(4):
                 sim.env_step(dev(acts[t], dtype), comm=sim.comm)
             res.append(out + list(sim.host()) + [sim.comm.cpu().numpy()])
-        lib.mpe_debug_force_tile_kernel(0)
+        set_force_tile(0)
         for x, y in zip(*res):
             assert np.array_equal(x, y, equal_nan=True)
 

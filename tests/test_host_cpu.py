@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_hip._LIB_PATH)
     for n in names:
         assert hasattr(raw, n), 'libmpe_hip.so does not export %s' % n
-    assert _hip.lib.mpe_abi_version() == _hip.ABI_VERSION == 5
+    assert _hip.lib.mpe_abi_version() == _hip.ABI_VERSION == 6
     assert _hip.lib.mpe_desc_sizeof() == ctypes.sizeof(_hip.ScenarioDesc)
 
 
@@ -57,7 +57,7 @@ def test_observation_geometry_matches_oracle(mk):
     assert [_hip.lib.mpe_obs_row0(d, i) for i in range(spec.n_agents)] == list(np.cumsum([0] + dims[:-1]))
     assert _hip.lib.mpe_info_width(d) == spec.info_width
     assert _hip.lib.mpe_stats_width(d) == 2 * spec.n_agents + 2
-    assert _hip.lib.mpe_stats_rows(d, 1000, 4) >= 1
+    assert _hip.lib.mpe_stats_rows(d, 1000, 4, 0) >= 1
     # action rows: 5 physical entries + dim_c comm entries for non-silent agents (environment.py:42-76)
     adims = [_hip.lib.mpe_act_dim(d, i) for i in range(spec.n_agents)]
     assert adims == spec.act_dims

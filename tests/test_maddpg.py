@@ -180,3 +180,79 @@ def test_fused_actor_kernel_matches_torch(in_dim, sizes):
         p = torch.softmax(net(obs[:1])[0, :sizes[0]], 0)
     freq = torch.bincount(acts.argmax(1), minlength=sizes[0]).float() / acts.shape[0]
     assert float((freq - p).abs().max()) < 0.01
+
+
+def test_philox_open_interval_conversion_never_returns_one():
+    """mpe_actor_kernel.h:philox_open01 restated in numpy float32: ((w >> 9) + 0.5) * 2^-23.  The 24-bit form
+    ((w >> 8) + 0.5) * 2^-24 rounds to exactly 1.0 for w = 0xFFFFFFFF (round-to-even tie) -> log(-log(1)) = -inf
+    -> NaN action about once per step at 1 Mi envs; the 23-bit form is exact."""
+    w = np.array([0xFFFFFFFF, 0, 0x80000000, 0xFFFFFE00], dtype=np.uint32)
+    old = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    new = ((w >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    assert old[0] == np.float32(1.0)                                    # the bug this replaces
+    assert new.dtype == np.float32 and new.max() < 1.0 and new.min() > 0.0
+    assert new[0] == np.float32(1.0) - np.float32(2.0 ** -24) and new[1] == np.float32(2.0 ** -24)
+    g = -np.log(-np.log(new.astype(np.float64)))
+    assert np.isfinite(g).all()
+
+
+@pytest.mark.gpu
+def test_fused_actor_extreme_uniforms_and_sharded_noise():
+    """(a) the extreme values the uniform conversion can produce (2^-24 and 1 - 2^-24, i.e. Philox words 0 and
+    0xFFFFFFFF) give finite actions that sum to 1 per sub-space; (b) the kernel's own draw is finite everywhere on
+    a large batch; (c) the draw is keyed by the GLOBAL env id: shards [0, B) and [B, 2B) with env_id0 = 0 / B
+    reproduce the single 2B-env call bit for bit (env-sharded multi-GPU runs explore identically whatever the
+    world size)."""
+    from marl_amd.maddpg import actor_forward, pack_actor
+    torch.manual_seed(5)
+    sizes, in_dim = [5, 7], 20
+    net = mlp_model(in_dim, sum(sizes)).cuda()
+    packed = pack_actor(net)
+    B, ld = 4096, 4096 + 256
+    obs_rows = torch.randn(in_dim, ld, device='cuda')
+    obs = obs_rows[:, :B].t()
+    lo, hi = 2.0 ** -24, 1.0 - 2.0 ** -24
+    u = torch.full((B, sum(sizes)), hi, device='cuda')
+    u[::2] = lo
+    u[1::4, 0] = lo
+    got = actor_forward(packed, obs, sizes, u=u)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got[:, :5].sum(1), torch.ones(B, device='cuda'), atol=1e-5)
+    assert torch.allclose(got[:, 5:].sum(1), torch.ones(B, device='cuda'), atol=1e-5)
+    for c in range(1, 4):
+        own = actor_forward(packed, obs, sizes, seed=11, call_counter=c)
+        assert torch.isfinite(own).all()
+    # sharding: two half batches with their global env offsets == one call over the concatenation
+    B2 = 2 * B
+    rows2 = torch.randn(in_dim, B2 + 256, device='cuda')
+    whole = actor_forward(packed, rows2[:, :B2].t(), sizes, seed=3, call_counter=9, env_id0=1000)
+    first = actor_forward(packed, rows2[:, :B].t(), sizes, seed=3, call_counter=9, env_id0=1000)
+    second_rows = torch.zeros(in_dim, B + 256, device='cuda')
+    second_rows[:, :B] = rows2[:, B:B2]
+    second = actor_forward(packed, second_rows[:, :B].t(), sizes, seed=3, call_counter=9, env_id0=1000 + B)
+    assert torch.equal(whole[:B], first) and torch.equal(whole[B:], second)
+    wrong = actor_forward(packed, second_rows[:, :B].t(), sizes, seed=3, call_counter=9, env_id0=1000)
+    assert not torch.equal(whole[B:], wrong)
+
+
+@pytest.mark.gpu
+def test_trainer_noise_follows_seed_and_global_env_id():
+    """MADDPGAgentTrainer passes world.env_id0 and a seed derived from the run seed to the actor kernel."""
+    from marl_amd import make_env
+    from marl_amd.maddpg import MADDPGAgentTrainer
+    B = 512
+    env = make_env('simple_tag', num_envs=2 * B, dtype=torch.float32, seed=4)
+    obs_n = env.reset()
+    shapes = [env.observation_space[i].shape for i in range(env.n)]
+
+    def trainer(seed, env_id0):
+        torch.manual_seed(0)                                             # same weights
+        return MADDPGAgentTrainer('a', shapes, env.action_space, 0, _args(), replay_size=64, seed=seed, env_id0=env_id0)
+    whole = trainer(7, 0).action(obs_n[0])
+    rows = env.world.obs[:16]
+    lo = trainer(7, 0).action(rows[:, :B].t())
+    hi_rows = env.world.rows(16)
+    hi_rows[:, :B] = rows[:, B:2 * B]
+    hi = trainer(7, B).action(hi_rows[:, :B].t())
+    assert torch.equal(whole[:B], lo) and torch.equal(whole[B:], hi)
+    assert not torch.equal(whole, trainer(8, 0).action(obs_n[0]))         # the run seed matters
