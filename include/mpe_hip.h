@@ -92,6 +92,7 @@ extern "C" {
 #define MPE_ERR_ALIGN (-4)       /* a device pointer is not aligned to its element   */
 #define MPE_ERR_UNSUPPORTED (-5) /* e.g. movable landmarks, non-silent agents        */
 #define MPE_ERR_ARG (-6)         /* any other bad scalar argument                    */
+#define MPE_ERR_SCRATCH (-7)     /* batch needs more than the built-in scratch array (mpe_env_step_stats_static) */
 
 /* mpe_buffers.flags bits (per call; 0 = default behaviour) */
 #define MPE_FLAG_FORCE_TILE 1u   /* run the generic LDS-tile kernel even for a world that has a register-resident
@@ -351,6 +352,22 @@ int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim,
 int mpe_stats_width(const mpe_scenario_desc *desc);
 int64_t mpe_stats_rows(const mpe_scenario_desc *desc, int64_t B, int dtype_bytes, uint32_t flags);
 int mpe_stats_reduce(const double *stats, int64_t rows, int width, double *out, void *stream);
+
+/*
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): mpe_env_step_{f32,f64} (dtype_bytes = 4 / 8)
+ * followed by mpe_stats_reduce in one call, with the per-workgroup statistics rows -- the scratch the caller
+ * otherwise allocates as buf->stats -- kept in a file-scope device array of MPE_STATIC_SCRATCH_BYTES inside the
+ * library (every GPU the library runs on holds its own copy until the process ends).  buf->stats is ignored;
+ * stats_out: device double [mpe_stats_width(desc)], OVERWRITTEN with this step's sums (same layout and the
+ * same bits as mpe_stats_reduce over a zeroed buf->stats).  Calls no hipMalloc / hipFree / allocating routine.
+ * Limit: mpe_stats_rows(desc, B, dtype_bytes, buf->flags) * mpe_stats_width(desc) * 8 <= MPE_STATIC_SCRATCH_BYTES
+ * (simple_tag f32: B <= 3 355 392), else MPE_ERR_SCRATCH and nothing is launched.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not.
+ */
+#define MPE_STATIC_SCRATCH_BYTES (1 << 20)
+int mpe_env_step_stats_static(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,
+                              int dtype_bytes, double *stats_out, void *stream);
 
 #ifdef __cplusplus
 }

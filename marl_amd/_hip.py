@@ -132,6 +132,9 @@ def _load():
     L.mpe_stats_rows.argtypes = [dp, i64, ci, u32]
     L.mpe_stats_reduce.restype = ci
     L.mpe_stats_reduce.argtypes = [vp, i64, ci, vp, vp]
+    # desc, B, ld, buffers, dtype_bytes, stats_out, stream
+    L.mpe_env_step_stats_static.restype = ci
+    L.mpe_env_step_stats_static.argtypes = [dp, i64, i64, bp, ci, vp, vp]
     L.mpe_desc_sizeof.restype = i64
     L.mpe_desc_sizeof.argtypes = []
     if L.mpe_abi_version() != ABI_VERSION:

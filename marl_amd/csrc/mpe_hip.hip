@@ -111,6 +111,9 @@ extern "C" const char *mpe_strerror(int code) {
       return "unsupported world (movable landmarks / unknown scenario kind / comm actions outside the "
              "command-hierarchy scenarios)";
     case MPE_ERR_ARG: return "bad argument";
+    case MPE_ERR_SCRATCH:
+      return "batch too large for the built-in scratch array of mpe_env_step_stats_static (its statistics rows x "
+             "width must fit MPE_STATIC_SCRATCH_BYTES); use mpe_env_step_* with a caller-owned stats buffer";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
@@ -898,6 +901,66 @@ extern "C" int mpe_stats_reduce(const double *stats, int64_t rows, int width, do
   hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)width), dim3(256), 0, (hipStream_t)stream, stats, rows,
                      width, out);
   return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mpe_env_step_stats_static: fused env step + statistics reduce with the per-workgroup partial rows in a
+// file-scope device array instead of a caller-owned buffer (for callers that cannot allocate: HIP graph
+// capture, serving loops).  Calls no hipMalloc / hipFree.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kScratchDoubles = MPE_STATIC_SCRATCH_BYTES / sizeof(double);
+static __device__ __align__(256) double scratch[kScratchDoubles];
+// The array's name is a host-side stand-in, not a device address: each GPU holds its own copy at its own
+// address, looked up once per device with hipGetSymbolAddress and kept here.
+constexpr int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices];
+
+static int scratch_of_current_device(double **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return MPE_ERR_ARG;
+  double *ptr = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (ptr == nullptr) {
+    e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (ptr == nullptr) return (int)hipErrorInvalidSymbol;
+    __atomic_store_n(&g_scratch_ptr[dev], ptr, __ATOMIC_RELEASE);
+  }
+  *out = ptr;
+  return MPE_OK;
+}
+
+template <typename T>
+static int env_step_stats_static_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const mpe_buffers *b,
+                                      double *stats_out, hipStream_t stream) {
+  KParams<T> p{};
+  int rc = bind_buffers<T>(h, B, ld, b, true, true, p);
+  if (rc) return rc;
+  const int width = 2 * h->n_agents + 2;
+  const int64_t rows = mpe_stats_rows(h, B, (int)sizeof(T), b->flags);
+  if (rows < 0) return (int)rows;
+  if ((uint64_t)rows * (uint64_t)width > kScratchDoubles) return MPE_ERR_SCRATCH;
+  double *ptr = nullptr;
+  rc = scratch_of_current_device(&ptr);
+  if (rc) return rc;
+  // the array keeps the previous call's partial sums and the kernels accumulate (+=): clear what this call uses
+  hipError_t e = hipMemsetAsync(ptr, 0, (size_t)rows * width * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  p.stats = ptr;
+  rc = launch<T, true, true>(h, p, b->flags, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)width), dim3(256), 0, stream, ptr, rows, width, stats_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, int64_t ld, const mpe_buffers *b,
+                                         int dtype_bytes, double *stats_out, void *stream) {
+  if (!stats_out) return MPE_ERR_NULL;
+  if (((uintptr_t)stats_out % sizeof(double)) != 0) return MPE_ERR_ALIGN;
+  if (dtype_bytes == 4) return env_step_stats_static_impl<float>(d, B, ld, b, stats_out, (hipStream_t)stream);
+  if (dtype_bytes == 8) return env_step_stats_static_impl<double>(d, B, ld, b, stats_out, (hipStream_t)stream);
+  return MPE_ERR_ARG;
 }
 
 // ------------------------------------------------------------------------------------------------
