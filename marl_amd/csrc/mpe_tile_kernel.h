@@ -25,14 +25,145 @@
 
 namespace mpe {
 
+// 16-byte vector of T: 4 floats / 2 doubles = the envs one lane covers in the vectorised observation phase
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+// One 16-byte streaming store (the lane's VEC consecutive envs of one row), or, for a lane of the last tile that
+// reaches past B / a row stride or base pointer that is not 16-byte aligned, its valid elements one by one.
+template <typename T>
+__device__ __forceinline__ void st_stream_vec(T *ptr, typename Vec16<T>::type v, int nvalid, bool full) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (full) {
+#ifdef MPE_NO_NT_STORE
+    *reinterpret_cast<typename Vec16<T>::type *>(ptr) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<typename Vec16<T>::type *>(ptr));
+#endif
+  } else {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c)
+      if (c < nvalid) st_stream(ptr + c, v[c]);
+  }
+}
+
+// One section of an agent's observation: rows kk = 0 .. nrows-1 copy the LDS rows src + kk (+ 2 from kk >= skip on:
+// the observer's own two rows are left out of "other agents"), minus the observer's position when REL.  Four rows per
+// trip: lane (r, q) handles row b0 + r, envs VEC q .. VEC q + VEC - 1, so one store instruction writes four 256-byte
+// row segments and one ds_read_b128 per lane fetches them (1 KiB of LDS per wave-instruction, conflict-free).
+// Sections start on even rows and b0 is a multiple of 4, so row parity (x / y) is r & 1 throughout.
+template <typename T, int TILE, bool REL, bool FULL>
+__device__ __forceinline__ void obs_section(T *lane_out, int64_t ld, const T *lane_src, int nrows, int skip, int r,
+                                            typename Vec16<T>::type pi, int nvalid) {
+  typedef typename Vec16<T>::type VT;
+  // two blocks per trip: both LDS reads are in flight before the first subtraction waits for its data
+  int b0 = 0;
+  for (; b0 + 4 < nrows; b0 += 8) {
+    const int k0 = b0 + r, k1 = b0 + 4 + r;
+    const bool ok1 = k1 < nrows;
+    const int row0 = k0 >= skip ? b0 + 2 : b0;                   // k0 < nrows: only the last block of a section is partial
+    const int row1 = ok1 ? (k1 >= skip ? b0 + 6 : b0 + 4) : 0;   // rows beyond the section: read row 0, store nothing
+    VT v0 = *reinterpret_cast<const VT *>(lane_src + row0 * TILE);
+    VT v1 = *reinterpret_cast<const VT *>(lane_src + row1 * TILE);
+    if (REL) { v0 = v0 - pi; v1 = v1 - pi; }
+    st_stream_vec<T>(lane_out + (int64_t)b0 * ld, v0, nvalid, FULL);
+    if (ok1) st_stream_vec<T>(lane_out + (int64_t)(b0 + 4) * ld, v1, nvalid, FULL);
+  }
+  if (b0 < nrows) {
+    const int kk = b0 + r;
+    const bool ok = kk < nrows;
+    const int row = ok ? (kk >= skip ? b0 + 2 : b0) : 0;
+    VT v = *reinterpret_cast<const VT *>(lane_src + row * TILE);
+    if (REL) v = v - pi;
+    if (ok) st_stream_vec<T>(lane_out + (int64_t)b0 * ld, v, nvalid, FULL);
+  }
+}
+
+// Observation rows of simple_tag (simple_tag.py:131-147) / simple_spread (simple_spread.py:83-99) for one tile, all
+// agents: [vel_i, pos_i, landmarks - pos_i, other agents - pos_i, (tag) velocities of the other good agents /
+// (spread) dim_c (A-1) zeros].  Wavefront w takes agents w, w + NW, ...; 94 % of the scaled world's HBM traffic is
+// issued here, as 16-byte stores (global_store_dwordx4), 4 rows per instruction.
+template <typename T, int TILE, int THREADS, bool TAG, bool FULL>
+__device__ __forceinline__ void obs_rows_vec_impl(const KParams<T> &p, const T *sPos, const T *sVel, int64_t tile) {
+  constexpr int VEC = 16 / sizeof(T);
+  static_assert(TILE == 16 * VEC, "a row segment of the tile is 16 lanes x 16 bytes");
+  typedef typename Vec16<T>::type VT;
+  constexpr int NW = THREADS / 64;
+  const DevDesc<T> &d = p.d;
+  const int A = d.A, L = d.L;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l64 = threadIdx.x & 63, q = l64 & 15, r = l64 >> 4;
+  const int64_t ld = p.ld;
+  const int64_t env0 = tile * TILE + VEC * q;
+  const int64_t left = p.B - env0;
+  const int nvalid = left >= VEC ? VEC : (left > 0 ? (int)left : 0);
+  const int lcol = VEC * q;
+  for (int i = wv; i < A; i += NW) {
+    T *o = p.obs + (int64_t)(d.obs_row0[i] + r) * ld + env0;  // this lane's row of block 0
+    const VT pi = *reinterpret_cast<const VT *>(sPos + (2 * i + (r & 1)) * TILE + lcol);
+    {  // [vel_i, pos_i]
+      const T *s0 = (r < 2 ? sVel : sPos) + (2 * i + (r & 1)) * TILE + lcol;
+      st_stream_vec<T>(o, *reinterpret_cast<const VT *>(s0), nvalid, FULL);
+      o += 4 * ld;
+    }
+    obs_section<T, TILE, true, FULL>(o, ld, sPos + (2 * A + r) * TILE + lcol, 2 * L, 0x7fffffff, r, pi, nvalid);
+    o += (int64_t)(2 * L) * ld;
+    obs_section<T, TILE, true, FULL>(o, ld, sPos + r * TILE + lcol, 2 * (A - 1), 2 * i, r, pi, nvalid);
+    o += (int64_t)(2 * (A - 1)) * ld;
+    if (TAG) {
+      // good agents other than i, in agent order: two per trip (scalar lookups in the descriptor's good list)
+      const bool i_good = !bit(d.adversary, i);
+      // position of i in the good list = number of good agents below i (no entry is skipped for an adversary)
+      int rank = d.n_good;
+      if (i_good) {
+        const uint32_t lo = i < 32 ? ~d.adversary[0] & ((1u << (i & 31)) - 1u) : ~d.adversary[0];
+        const uint32_t hi = i < 32 ? 0u : ~d.adversary[1] & ((1u << (i & 31)) - 1u);
+        rank = __builtin_popcount(lo) + __builtin_popcount(hi);
+      }
+      const int nrows = 2 * (d.n_good - (i_good ? 1 : 0));
+      for (int b0 = 0; b0 < nrows; b0 += 4) {
+        const int ga = b0 >> 1, gb = ga + 1;
+        const int ja = d.good_list[ga + (ga >= rank ? 1 : 0)];
+        const int jb = 2 * gb < nrows ? d.good_list[gb + (gb >= rank ? 1 : 0)] : ja;
+        const bool ok = b0 + r < nrows;
+        const VT v = *reinterpret_cast<const VT *>(sVel + (2 * (r >> 1 ? jb : ja) + (r & 1)) * TILE + lcol);
+        if (ok) st_stream_vec<T>(o + (int64_t)b0 * ld, v, nvalid, FULL);
+      }
+    } else {
+      const int nrows = d.dim_c * (A - 1);  // other.state.c of silent agents (simple_spread.py:95)
+      VT z;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) z[c] = T(0);
+      for (int b0 = 0; b0 < nrows; b0 += 4)
+        if (b0 + r < nrows) st_stream_vec<T>(o + (int64_t)b0 * ld, z, nvalid, FULL);
+    }
+  }
+}
+
+template <typename T, int TILE, int THREADS, bool TAG>
+__device__ __forceinline__ void obs_rows_vec(const KParams<T> &p, const T *sPos, const T *sVel, int64_t tile) {
+  constexpr int VEC = 16 / sizeof(T);
+  // whole 16-byte stores everywhere (workgroup-uniform test): every env of the tile exists, rows and base are aligned
+  const bool full = (tile + 1) * TILE <= p.B && (p.ld % VEC) == 0 && (reinterpret_cast<uintptr_t>(p.obs) % 16) == 0;
+  if (full) obs_rows_vec_impl<T, TILE, THREADS, TAG, true>(p, sPos, sVel, tile);
+  else obs_rows_vec_impl<T, TILE, THREADS, TAG, false>(p, sPos, sVel, tile);
+}
+
 // HIER: the world may carry ragged actions / speaking agents (kinds MPE_HIER_PURSUIT, the only one with
 // force_id / forced_id, MPE_SPEAKER_LISTENER and MPE_SIMPLE_REFERENCE; mpe_hip.hip:mpe_desc_check).  A template flag so that the
 // stock kinds do not pay for its branches in the per-agent loops (scaled simple_tag: 3.80 -> 3.50 ms).
-template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER>
+//
+// KIND: MPE_SIMPLE_TAG / MPE_SIMPLE_SPREAD compile the scenario in (the north-star worlds at any size: the other
+// kinds' branches disappear, and with them most of the live scalars: the all-kinds build of the scaled simple_tag
+// step needed 106 SGPRs + 134 spilled to VGPR lanes); -1 = the kind is read from the descriptor at run time.
+template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER, int KIND>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
   constexpr int NCH = THREADS / TILE;
+  static_assert(!HIER || KIND < 0, "the ragged kinds are not specialised");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevDesc<T> &d = p.d;
+  const int kind = KIND >= 0 ? KIND : d.kind;
   const int A = d.A, L = d.L, E = d.E;
   T *sPos = reinterpret_cast<T *>(smem_raw);
   T *sLf = sPos + 2 * E * TILE;
@@ -57,6 +188,28 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
 
     // ---- phase 0 ------------------------------------------------------------------------------
     for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = p.pos[(int64_t)r * ld + ge];
+    // Inputs of one agent of one env: old velocity, the four action entries that matter, u_noise normals.  Fetched one
+    // agent ahead of the pair loop (and the first one here, beside the position loads), so that the HBM latency of
+    // these read-once rows -- several microseconds while the chip streams observations -- hides behind compute.
+    struct AgentIn { T vx, vy, a1, a2, a3, a4, nx, ny; };
+    auto fetch = [&](int a, AgentIn &in) {
+      in.vx = p.vel[(int64_t)(2 * a) * ld + ge];
+      in.vy = p.vel[(int64_t)(2 * a + 1) * ld + ge];
+      in.a1 = in.a2 = in.a3 = in.a4 = in.nx = in.ny = T(0);
+      if (bit(d.movable, a)) {
+        const T *ar = p.act + (int64_t)(HIER ? d.act_row0[a] : 5 * a) * ld + ge;  // environment.py:188-190
+        in.a1 = ld_stream(ar + ld);
+        in.a2 = ld_stream(ar + 2 * ld);
+        in.a3 = ld_stream(ar + 3 * ld);
+        in.a4 = ld_stream(ar + 4 * ld);
+        if (p.noise != nullptr && d.u_noise[a] != T(0)) {
+          in.nx = ld_stream(p.noise + (int64_t)(2 * a) * ld + ge);
+          in.ny = ld_stream(p.noise + (int64_t)(2 * a + 1) * ld + ge);
+        }
+      }
+    };
+    AgentIn nxt;
+    if (DO_STEP && chunk < A) fetch(chunk, nxt);
     if (!DO_STEP) {
       for (int r = chunk; r < 2 * A; r += NCH) sVel[r * TILE + lane] = p.vel[(int64_t)r * ld + ge];
       if (has_lf)
@@ -67,17 +220,17 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
     if (DO_STEP) {
       // ---- phase 1: forces + velocity ---------------------------------------------------------
       for (int a = chunk; a < A; a += NCH) {
-        T vx = p.vel[(int64_t)(2 * a) * ld + ge];
-        T vy = p.vel[(int64_t)(2 * a + 1) * ld + ge];
+        const AgentIn cur = nxt;
+        if (a + NCH < A) fetch(a + NCH, nxt);
+        T vx = cur.vx, vy = cur.vy;
         if (bit(d.movable, a)) {
           // environment.py:188-196
-          const T *ar = p.act + (int64_t)(HIER ? d.act_row0[a] : 5 * a) * ld + ge;
-          T Fx = (ar[1 * ld] - ar[2 * ld]) * d.accel[a];
-          T Fy = (ar[3 * ld] - ar[4 * ld]) * d.accel[a];
+          T Fx = (cur.a1 - cur.a2) * d.accel[a];
+          T Fy = (cur.a3 - cur.a4) * d.accel[a];
           // core.py:147-148
           if (p.noise != nullptr && d.u_noise[a] != T(0)) {
-            Fx = Fx + p.noise[(int64_t)(2 * a) * ld + ge] * d.u_noise[a];
-            Fy = Fy + p.noise[(int64_t)(2 * a + 1) * ld + ge] * d.u_noise[a];
+            Fx = Fx + cur.nx * d.u_noise[a];
+            Fy = Fy + cur.ny * d.u_noise[a];
           }
           // core.py:153-194
           if (has_lf) {
@@ -169,7 +322,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
                  want_stats = p.stats != nullptr;
       double *srow = want_stats ? p.stats + (int64_t)blockIdx.x * (2 * A + 2) : nullptr;
       // goal landmark of this env (agent.goal_a), scenarios with a goal only
-      const bool has_goal = kind_has_goal(d.kind);
+      const bool has_goal = kind_has_goal(kind);
       int goal = 0;
       T gx = T(0), gy = T(0);
       if (has_goal) {
@@ -179,14 +332,17 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         gy = sPos[(2 * (A + goal) + 1) * TILE + lane];
       }
       // ---- phase 3a: observations (simple_tag.py:131-147 / simple_spread.py:83-99) -----------------
+      constexpr bool VEC_OBS = KIND == MPE_SIMPLE_TAG || KIND == MPE_SIMPLE_SPREAD;
 #ifdef MPE_ABL_NO_OBS
       if (p.obs != nullptr && active && p.B < 0) {
 #else
-      if (p.obs != nullptr && active) {
+      if (VEC_OBS && p.obs != nullptr) {
+        obs_rows_vec<T, TILE, THREADS, KIND == MPE_SIMPLE_TAG>(p, sPos, sVel, tile);
+      } else if (p.obs != nullptr && active) {
 #endif
         // simple_world_comm: which agents stand in forest 0 / forest 1 (is_collision, :240-245,258-259)
         uint64_t in_f0 = 0, in_f1 = 0;
-        if (HIER && d.kind == MPE_WORLD_COMM) {
+        if (HIER && kind == MPE_WORLD_COMM) {
           const int f0 = E - 2;
           const T f0x = sPos[(2 * f0) * TILE + lane], f0y = sPos[(2 * f0 + 1) * TILE + lane];
           const T f1x = sPos[(2 * f0 + 2) * TILE + lane], f1y = sPos[(2 * f0 + 3) * TILE + lane];
@@ -199,7 +355,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         for (int i = chunk; i < A; i += NCH) {
           T *o = p.obs + (int64_t)d.obs_row0[i] * ld + env;
           const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
-          if (HIER && d.kind == MPE_WORLD_COMM) {
+          if (HIER && kind == MPE_WORLD_COMM) {
             // simple_world_comm.py:230-313
             st_stream(o, sVel[(2 * i) * TILE + lane]);
             st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
@@ -249,7 +405,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             continue;
           }
-          if (HIER && d.kind == MPE_SIMPLE_CRYPTO) {
+          if (HIER && kind == MPE_SIMPLE_CRYPTO) {
             // simple_crypto.py:124-171: speaker [goal colour, key]; listener [key, speaker's c]; adversary [speaker's c]
             const int C = d.dim_c;
             const int gl = p.goal[ge], key = p.goal[ld + ge];
@@ -267,9 +423,9 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             continue;
           }
-          if (HIER && kind_is_comm(d.kind)) {
+          if (HIER && kind_is_comm(kind)) {
             // simple_speaker_listener.py:72-94 / simple_reference.py:62-89
-            const bool ref = d.kind == MPE_SIMPLE_REFERENCE;
+            const bool ref = kind == MPE_SIMPLE_REFERENCE;
             int g = p.goal[(int64_t)(ref ? i : 0) * ld + ge];  // agent.goal_b
             g = g < 0 ? 0 : (g >= L ? L - 1 : g);
             const T base = ref ? T(0.25) : T(0.15), hi = ref ? T(0.75) : T(0.65);  // landmark.color tables
@@ -301,7 +457,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             continue;
           }
-          if (HIER && d.kind == MPE_HIER_MOVING) {
+          if (HIER && kind == MPE_HIER_MOVING) {
             // L1F4_MovingTarget.py:214-258 (S1L2F4_MovingTarget.py: radius only, :227)
             st_stream(o, sVel[(2 * i) * TILE + lane]);
             st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
@@ -338,7 +494,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             continue;
           }
-          if (HIER && d.kind == MPE_HIER_PURSUIT) {
+          if (HIER && kind == MPE_HIER_PURSUIT) {
             // L1F2_3Targets_100observe.py:198-253 (same text in every L1F*/S1L* file)
             st_stream(o, sVel[(2 * i) * TILE + lane]);
             st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
@@ -396,7 +552,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             }
             continue;
           }
-          if (d.kind == MPE_SIMPLE_TAG || d.kind == MPE_SIMPLE_SPREAD) {
+          if (kind == MPE_SIMPLE_TAG || kind == MPE_SIMPLE_SPREAD) {
             st_stream(o, sVel[(2 * i) * TILE + lane]);
             st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
             st_stream(o + 2 * ld, pix);
@@ -405,7 +561,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           } else {
             // simple.py:45-50 / simple_adversary.py:122-140 / simple_push.py:84-104
             const bool i_good = !bit(d.adversary, i);
-            if (d.kind != MPE_SIMPLE_ADVERSARY) {
+            if (kind != MPE_SIMPLE_ADVERSARY) {
               st_stream(o, sVel[(2 * i) * TILE + lane]);
               st_stream(o + ld, sVel[(2 * i + 1) * TILE + lane]);
               o += 2 * ld;
@@ -414,7 +570,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               st_stream(o, gx - pix);
               st_stream(o + ld, gy - piy);
               o += 2 * ld;
-              if (d.kind == MPE_SIMPLE_PUSH) {  // agent.color (simple_push.py:51-56)
+              if (kind == MPE_SIMPLE_PUSH) {  // agent.color (simple_push.py:51-56)
                 for (int k = 0; k < 3; ++k) { st_stream(o, k == goal + 1 ? T(0.25) + T(0.5) : T(0.25)); o += ld; }
               }
             }
@@ -424,11 +580,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             st_stream(o + ld, sPos[(2 * l + 1) * TILE + lane] - piy);
             o += 2 * ld;
           }
-          if (d.kind == MPE_SIMPLE_PUSH && !bit(d.adversary, i)) {  // landmark.color (simple_push.py:43-45)
+          if (kind == MPE_SIMPLE_PUSH && !bit(d.adversary, i)) {  // landmark.color (simple_push.py:43-45)
             for (int l = 0; l < L; ++l)
               for (int k = 0; k < 3; ++k) { st_stream(o, k == l + 1 ? T(0.1) + T(0.8) : T(0.1)); o += ld; }
           }
-          if (d.kind != MPE_SIMPLE) {
+          if (kind != MPE_SIMPLE) {
             for (int j = 0; j < A; ++j) {
               if (j == i) continue;
               st_stream(o, sPos[(2 * j) * TILE + lane] - pix);
@@ -436,14 +592,14 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               o += 2 * ld;
             }
           }
-          if (d.kind == MPE_SIMPLE_TAG) {
+          if (kind == MPE_SIMPLE_TAG) {
             for (int j = 0; j < A; ++j) {
               if (j == i || bit(d.adversary, j)) continue;
               st_stream(o, sVel[(2 * j) * TILE + lane]);
               st_stream(o + ld, sVel[(2 * j + 1) * TILE + lane]);
               o += 2 * ld;
             }
-          } else if (d.kind == MPE_SIMPLE_SPREAD) {
+          } else if (kind == MPE_SIMPLE_SPREAD) {
             for (int z = 0; z < d.dim_c * (A - 1); ++z) { st_stream(o, T(0)); o += ld; }
           }
         }
@@ -455,7 +611,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
 #else
       if (want_rew || want_info || want_stats) {
 #endif
-        if (d.kind == MPE_SIMPLE_TAG) {
+        if (kind == MPE_SIMPLE_TAG) {
           // hit(g,a) = is_collision(good g, adversary a) (simple_tag.py:69-73), each pair evaluated
           // once by the chunk that owns g; per-adversary counts meet in LDS (ds_add, rare).
           int *sCnt = reinterpret_cast<int *>(sAux);        // [n_adv][TILE]
@@ -512,7 +668,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
-        } else if (HIER && d.kind == MPE_WORLD_COMM) {
+        } else if (HIER && kind == MPE_WORLD_COMM) {
           // simple_world_comm.py:119-204.  Every agent's sums are evaluated by the chunk that owns the agent, in
           // the reference's order (the running reward is not an integer here: -0.1 * min distance comes first).
           const int food0 = E - d.n_forests - d.n_food, food1 = E - d.n_forests;
@@ -568,7 +724,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
-        } else if (HIER && d.kind == MPE_SIMPLE_CRYPTO) {
+        } else if (HIER && kind == MPE_SIMPLE_CRYPTO) {
           // simple_crypto.py:78-121: squared error of Eve's / Bob's message against the goal colour; an
           // all-zero message switches its term off.  Every chunk recomputes the two sums (tiny world).
           const int C = d.dim_c;
@@ -608,10 +764,10 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) srow[2 * A + 1] += s_n;
           }
-        } else if (HIER && kind_is_comm(d.kind)) {
+        } else if (HIER && kind_is_comm(kind)) {
           // simple_speaker_listener.py:66-70 (both agents: listener to agent 0's goal) /
           // simple_reference.py:56-60 (agent i: the OTHER agent to agent i's goal)
-          const bool ref = d.kind == MPE_SIMPLE_REFERENCE;
+          const bool ref = kind == MPE_SIMPLE_REFERENCE;
           for (int i = chunk; i < A; i += NCH) {
             int g = p.goal[(int64_t)(ref ? i : 0) * ld + ge];
             g = g < 0 ? 0 : (g >= L ? L - 1 : g);
@@ -628,7 +784,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) srow[2 * A + 1] += s_n;
           }
-        } else if (HIER && d.kind == MPE_HIER_MOVING) {
+        } else if (HIER && kind == MPE_HIER_MOVING) {
           // L1F4_MovingTarget.py:157-212.  Every adversary gets the same sum: 10 per (good agent, anybody)
           // contact, +50 after each good agent once the running count has reached 4.  Integers: exact.
           auto hit = [&](int a, int b) {
@@ -667,7 +823,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
-        } else if (HIER && d.kind == MPE_HIER_PURSUIT) {
+        } else if (HIER && kind == MPE_HIER_PURSUIT) {
           // n_o = number of targets agent o touches (is_collision, L1F2_3Targets_100observe.py:150-154)
           int *sCnt = reinterpret_cast<int *>(sAux);  // [A][TILE]
           for (int o = chunk; o < A; o += NCH) {
@@ -725,7 +881,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
           }
-        } else if (d.kind != MPE_SIMPLE_SPREAD) {
+        } else if (kind != MPE_SIMPLE_SPREAD) {
           // simple.py:41-43 / simple_adversary.py:58-119 / simple_push.py:66-82.  The per-env scalars
           // (nearest good agent to the goal, summed adversary distances) are recomputed by every
           // chunk: these worlds are small.
@@ -736,7 +892,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               const T dist = t_sqrt<T>(sqdist<T>(sPos[(2 * g) * TILE + lane], sPos[(2 * g + 1) * TILE + lane], gx, gy));
               m = (gi == 0 || dist < m) ? dist : m;
             }
-            if (d.kind == MPE_SIMPLE_ADVERSARY)
+            if (kind == MPE_SIMPLE_ADVERSARY)
               for (int ai = 0; ai < d.n_adv; ++ai) {
                 const int a = d.adv_list[ai];
                 adv_rew = adv_rew + t_sqrt<T>(sqdist<T>(sPos[(2 * a) * TILE + lane], sPos[(2 * a + 1) * TILE + lane], gx, gy));
@@ -746,9 +902,9 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
             const bool i_adv = bit(d.adversary, i);
             T r_i;
-            if (d.kind == MPE_SIMPLE) {
+            if (kind == MPE_SIMPLE) {
               r_i = -sqdist<T>(pix, piy, sPos[(2 * A) * TILE + lane], sPos[(2 * A + 1) * TILE + lane]);
-            } else if (d.kind == MPE_SIMPLE_ADVERSARY) {
+            } else if (kind == MPE_SIMPLE_ADVERSARY) {
               r_i = i_adv ? -sqdist<T>(pix, piy, gx, gy) : -m + adv_rew;
             } else {
               const T dg = t_sqrt<T>(sqdist<T>(pix, piy, gx, gy));

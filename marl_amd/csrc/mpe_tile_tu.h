@@ -27,11 +27,11 @@ static int grant_lds(K kern, size_t lds, size_t *granted /*[kMaxDevices]*/) {
   return 0;
 }
 
-template <typename T, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER>
+template <typename T, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER, int KIND>
 static int launch_tile_k(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   constexpr int TILE = tile_envs<T>();
   const size_t lds = tile_lds_bytes<T>(h, THREADS);
-  auto kern = tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, HIER>;
+  auto kern = tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, HIER, KIND>;
   if (lds > 64 * 1024) {
     if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
     static size_t granted[64] = {};
@@ -45,8 +45,11 @@ static int launch_tile_k(const mpe_scenario_desc *h, const KParams<T> &p, hipStr
 
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
-  return tile_kind_is_ragged(h->kind) ? launch_tile_k<T, THREADS, DO_STEP, DO_OBS, true>(h, p, s)
-                                      : launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false>(h, p, s);
+  if (tile_kind_is_ragged(h->kind)) return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, true, -1>(h, p, s);
+  // the north-star scenarios get their own instantiation (mpe_tile_kernel.h: KIND)
+  if (h->kind == MPE_SIMPLE_TAG) return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_TAG>(h, p, s);
+  if (h->kind == MPE_SIMPLE_SPREAD) return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_SPREAD>(h, p, s);
+  return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, -1>(h, p, s);
 }
 
 template <typename T, bool DO_STEP, bool DO_OBS>
