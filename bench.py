@@ -5,14 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one MultiAgentEnv.step() over the rank's whole batch (action decode + World.step +
-observation + reward + benchmark info for all agents, one fused HIP launch), with the periodic
-Scenario.reset_world + observation gather every 25 steps inside the timed region, episode
-statistics accumulated on device and all-reduced (RCCL) once per episode.  Inputs (state, a
-rotating pool of action tensors) are resident in HBM before the timed region.
+observation + reward + benchmark info for all agents, one fused HIP launch).  Episodes are 25 steps
+(BASELINE.md); at every episode boundary the loop reads the episode statistics (deterministic on-device
+reduce + one all-reduce over RCCL) and calls env.reset() (Scenario.reset_world + observation gather).  The
+timed region is phased so that it always contains such a boundary (the JSON line says how many).  Inputs
+(state, a rotating pool of action tensors) are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, fused
-env-step kernel, HIP-event brackets around the launches inside the timed region) and `cpu_baseline` (the
-oracle's serial numpy loop on one host core, rank 0 at N=1 only).
+The runs of consecutive steps between boundaries are replayed as HIP graphs (marl_amd/graph.py; --no-graph
+= one Python call per step): for small batches the host path of a step costs more than its kernel.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, fused env-step
+kernel, HIP-event brackets around the launches inside the timed region), `cpu_baseline` (the oracle's serial
+numpy loop on one host core and on all of the box's cores, rank 0 at N=1 only) and, at N=1 with the default
+workload, `other_configs`: short runs of the other single-GPU BASELINE configs, each with its own roofline.
 """
 import argparse
 import json
@@ -28,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md, Chip-level parameters)
 EPISODE_LEN = 25
+POOL = 5                  # resident action tensors, rotated by position in the episode (divides EPISODE_LEN)
 
 WORKLOADS = {
     # name: (scenario, scenario kwargs, envs per GPU, dtype)
@@ -52,6 +58,8 @@ WORKLOADS = {
     'L1F4_MovingTarget_1M_f32': ('L1F4_MovingTarget', {}, 1 << 20, torch.float32),
     'S1L2F4_MovingTarget_1M_f32': ('S1L2F4_MovingTarget', {}, 1 << 20, torch.float32),
 }
+# the other single-GPU configurations of BASELINE.json (+ the fp64 parity mode at the headline size): (name, steps, warmup)
+OTHER_CONFIGS = (('simple_spread_64k_f64', 500, 50), ('scaled_tag_256k_f32', 100, 25), ('simple_tag_1M_f64', 250, 25))
 
 
 def algorithmic_elems(env, with_info=True):
@@ -77,23 +85,26 @@ def measured_traffic(workload):
         return None
     ks = json.load(open(path))['kernels']
 
-    def is_fused(name):      # template tails: small/hier <..., DO_STEP, DO_OBS>, tile <..., DO_STEP, DO_OBS, HIER>
+    def is_fused(name):      # template tails: small/hier <..., DO_STEP, DO_OBS>, tile <..., DO_STEP, DO_OBS, HIER[, KIND]>
         args = name[name.index('<') + 1:name.rindex('>(')].split(', ')
-        return (args[-3:-1] if 'tile_kernel' in name else args[-2:]) == ['true', 'true']
+        if 'tile_kernel' in name:
+            return args[3:5] == ['true', 'true']
+        return args[-2:] == ['true', 'true']
     fused = [v for k, v in ks.items() if 'mpe::' in k and is_fused(k)]
     return fused[0]['traffic_bytes'] if fused else None
 
 
-def cpu_baseline(seconds=12.0):
-    """Reference's serial numpy loop, restated (oracle.SerialEnv: one Python object per entity,
-    validated bit-exact against the reference), on ONE host core: simple_tag, 25-step episodes
-    incl. reset, random soft actions, benchmark=True -- the configuration of BASELINE.md."""
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's serial numpy loop, restated (oracle.SerialEnv), on the box's host cores
+# ------------------------------------------------------------------------------------------------------------
+def _cpu_worker(seconds, seed):
+    """simple_tag, 25-step episodes incl. reset, random soft actions, benchmark=True (BASELINE.md config 1);
+    returns (env-steps, seconds)."""
     import numpy as np
     from oracle import mpe_oracle as O
-    spec = O.simple_tag_spec()
-    env = O.SerialEnv(spec, benchmark=True)
-    rng = np.random.RandomState(0)
-    np.random.seed(0)
+    env = O.SerialEnv(O.simple_tag_spec(), benchmark=True)
+    rng = np.random.RandomState(seed)
+    np.random.seed(seed)
     env.reset()
     steps = 0
     t0 = time.perf_counter()
@@ -104,51 +115,73 @@ def cpu_baseline(seconds=12.0):
         steps += EPISODE_LEN
         dt = time.perf_counter() - t0
         if dt >= seconds:
-            break
-    return {'value': steps * env.n / dt, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
+            return steps, dt
+
+
+def _cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def host_cores():
+    """Cores this job may use: the affinity mask, capped by the box's per-job thread setting (the GPU box shows the
+    whole machine in os.cpu_count() and sets OMP_NUM_THREADS to the job's share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cap = os.environ.get('OMP_NUM_THREADS')
+    if cap and cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def cpu_baseline(seconds=12.0):
+    """Two legs, half the time each: ONE core (the reference is a serial single-thread loop), then the same loop
+    in `host_cores()` independent processes.  Must run before this process initialises the GPU (the
+    workers are forked)."""
+    import multiprocessing as mp
+    A = 4
+    s1, d1 = _cpu_worker(seconds / 2, 0)
+    cores = host_cores()
+    with mp.get_context('fork').Pool(cores) as pool:
+        res = pool.starmap(_cpu_worker, [(seconds / 2, 100 + i) for i in range(cores)])
+    multi = sum(s * A / d for s, d in res)
+    return {'value': s1 * A / d1, 'unit': 'agent-steps/s', 'cores': 1, 'kind': 'port',
             'sample': '%d env-steps of simple_tag (A=4, L=2), 25-step episodes incl. reset, benchmark=True, '
-                      'serial numpy loop (oracle.SerialEnv) on 1 host core of %d' % (steps, os.cpu_count())}
+                      'serial numpy loop (oracle.SerialEnv) on 1 host core' % s1,
+            'all_cores': {'value': multi, 'unit': 'agent-steps/s', 'cores': cores,
+                          'sample': '%d env-steps, the same loop in %d independent processes'
+                                    % (sum(s for s, _ in res), cores)},
+            'cpu_model': _cpu_model(), 'os_cpu_count': os.cpu_count()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=500)
-    ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--workload', default='simple_tag_1M_f32', choices=sorted(WORKLOADS))
-    ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
-    ap.add_argument('--action-buffers', type=int, default=4,
-                    help='resident action tensors rotated step by step (1 = the same tensor every step)')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                    help='nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the multi-rank path '
-                         'with every rank on whatever GPUs exist (ranks then share devices)')
-    ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (roofline from wall time)')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------
+# one workload
+# ------------------------------------------------------------------------------------------------------------
+def plan_segments(pos0, nsteps):
+    """The step positions pos0 .. pos0 + nsteps - 1 (position in the episode = index mod EPISODE_LEN) cut at the
+    episode boundaries: [(boundary_before, pos, length), ...]."""
+    out, t = [], pos0
+    end = pos0 + nsteps
+    while t < end:
+        pos = t % EPISODE_LEN
+        n = min(EPISODE_LEN - pos, end - t)
+        out.append((pos == 0, pos, n))
+        t += n
+    return out
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world_size = int(os.environ.get('WORLD_SIZE', 1))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-        args.gpus = world_size
-    dev_index = local_rank if args.backend == 'nccl' else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = torch.device('cuda', dev_index)
-    import torch.distributed as dist
-    if world_size > 1:
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
-        else:
-            dist.init_process_group('gloo')
 
+def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend, use_graph=True, use_events=True,
+                 actions='random'):
     from marl_amd import make_env, _hip
     from marl_amd.distributed import EpisodeStats, shard_range, summarize_stats
+    from marl_amd.graph import CapturedSteps
 
-    scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[args.workload]
-    B = args.envs or envs_per_gpu
+    scenario, kwargs, envs_per_gpu, dtype = WORKLOADS[name]
+    B = B or envs_per_gpu
     env_id0, _ = shard_range(B * world_size, rank, world_size)      # weak scaling: B per GPU fixed
     # scenarios without a (working) benchmark_data
     has_info = scenario not in ('simple', 'simple_push', 'simple_speaker_listener', 'simple_reference')
@@ -174,102 +207,195 @@ def main():
                     a[lo:hi] = torch.softmax(torch.randn(hi - lo, B, generator=gen, device=device, dtype=dtype), dim=0)
         return a
 
-    pool = [random_actions() for _ in range(args.action_buffers)]
+    def actions_by_env_id(k):
+        """Pool entry k as a function of the GLOBAL env id only (float64 sin hash -> softmax per sub-space): a batch
+        sharded over ranks then sees exactly the actions of the unsharded batch (tests/test_gpu_sharded.py)."""
+        w = env.world
+        a = w.new_action_buffer()
+        rows = a.reshape(-1, a.shape[-1])                    # [act_total, B] view of the SoA rows
+        gid = torch.arange(env_id0 + 1, env_id0 + 1 + B, device=device, dtype=torch.float64)
+        for ag, r0, d in zip(w.agents, w.act_row0, w.act_dims):
+            nu = 5 if ag.movable else 0
+            for lo, hi in ((r0, r0 + nu), (r0 + nu, r0 + d)):
+                if hi > lo:
+                    freq = torch.arange(lo, hi, device=device, dtype=torch.float64) * 0.37 + 1.3 * k + 0.011
+                    rows[lo:hi] = torch.softmax(3.0 * torch.sin(gid[None, :] * freq[:, None]), dim=0).to(dtype)
+        return a
+
+    pool = [actions_by_env_id(k) if actions == 'by-env-id' else random_actions() for k in range(POOL)]
     stats = EpisodeStats(env.world)
     stats_total = torch.zeros(2 * n + 2, dtype=torch.float64, device=device)
 
-    def run(nsteps, events=None, t_base=0):
-        """events: list collecting (start, end, n_launches) HIP-event brackets around each run of
-        consecutive fused env-step launches (one bracket per episode segment: an event between every
-        pair of launches would itself cost ~5 us of dispatch gap per step)."""
-        open_bracket = None
-        for t in range(nsteps):
-            tt = t_base + t
-            if tt % EPISODE_LEN == 0:
-                if open_bracket is not None:
-                    e1 = torch.cuda.Event(enable_timing=True)
-                    e1.record()
-                    events.append((open_bracket[0], e1, open_bracket[1]))
-                    open_bracket = None
-                if tt:
-                    stats_total.add_(stats.read())      # deterministic reduce + one all-reduce / episode
-                    stats.reset()
-                env.reset()
-            if events is not None and open_bracket is None:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                open_bracket = [e0, 0]
-            env.step(pool[tt % len(pool)])
-            if open_bracket is not None:
-                open_bracket[1] += 1
-        if open_bracket is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            events.append((open_bracket[0], e1, open_bracket[1]))
+    # phase: the timed region starts max(1, steps // 2) steps before an episode boundary, the warmup before that
+    pos_timed = (-max(1, steps // 2)) % EPISODE_LEN
+    pos_warm = (pos_timed - warmup) % EPISODE_LEN
+    segs_warm, segs_timed = plan_segments(pos_warm, warmup), plan_segments(pos_timed, steps)
 
-    def fence():
-        if world_size > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # prime every code path once (module load, first-launch costs, allocator) before the W warmup
+    # prime every code path once (module load, first-launch costs, allocator, graph captures) before the W warmup
     # steps, so that the timed region is steady state whatever W is
     env.reset()
     env.step(pool[0])
     stats_total.add_(stats.read())      # also loads torch's f64 add kernel (a ~20 ms one-time cost)
     stats_total.zero_()
     stats.reset()
+    graphs = {}
+    if use_graph:
+        for _, pos, length in segs_warm + segs_timed:
+            if (pos, length) not in graphs and length > 1:
+                graphs[(pos, length)] = CapturedSteps(env, [pool[(pos + k) % POOL] for k in range(length)])
+        stats.reset()
     torch.cuda.synchronize()
 
-    run(args.warmup)
-    events = None if args.no_events else []
+    counts = {'resets': 0, 'stats_reads': 0, 'graph_replays': 0, 'eager_steps': 0}
+
+    def run(segs, events=None, count=False):
+        """events: list collecting (start, end, n_launches) HIP-event brackets around each run of consecutive
+        fused env-step launches (an event between every pair of launches would itself cost ~5 us of dispatch
+        gap per step)."""
+        for boundary, pos, length in segs:
+            if boundary:
+                stats_total.add_(stats.read())      # deterministic reduce + one all-reduce / episode
+                stats.reset()
+                env.reset()
+                if count:
+                    counts['resets'] += 1
+                    counts['stats_reads'] += 1
+            if events is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            g = graphs.get((pos, length))
+            if g is not None:
+                g.replay()
+                if count:
+                    counts['graph_replays'] += 1
+            else:
+                for k in range(length):
+                    env.step(pool[(pos + k) % POOL])
+                if count:
+                    counts['eager_steps'] += length
+            if events is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                events.append((e0, e1, length))
+
+    def fence():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    env.reset()
+    run(segs_warm)
+    stats.reset()                       # the statistics in the JSON line cover exactly the timed steps
+    stats_total.zero_()
+    events = [] if use_events else None
     fence()
     t0 = time.perf_counter()
-    run(args.steps, events, t_base=args.warmup)
+    run(segs_timed, events, count=True)
     fence()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stats_total.add_(stats.read())
 
     elems = algorithmic_elems(env)
-    bytes_per_launch = elems * env.world.pos.element_size() * B
+    esize = env.world.pos.element_size()
+    bytes_per_launch = elems * esize * B
     if events:
         per = sorted(a.elapsed_time(b) / k for a, b, k in events)
         kern_ms = sum(a.elapsed_time(b) for a, b, k in events) / sum(k for a, b, k in events)
         kern_med = per[len(per) // 2]
     else:
-        kern_ms = kern_med = elapsed * 1e3 / args.steps
+        kern_ms = kern_med = elapsed * 1e3 / steps
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    out = {
+        'metric': 'agent-steps/sec (whole node) for batched simple_tag' if scenario == 'simple_tag' and not kwargs
+                  else 'agent-steps/sec (whole node), %s' % name,
+        'value': B * world_size * n * steps / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world_size, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': elapsed * 1e3 / steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if dtype == torch.float32 else 'f64', 'data': 'synthetic',
+        'config': {'workload': name, 'scenario': scenario, 'envs_per_gpu': B, 'row_stride': env.world.ld,
+                   'agents': n, 'entities': len(env.world.entities), 'episode_len': EPISODE_LEN,
+                   'actions': 'softmax(N(0,1)) soft one-hot, %d resident buffers rotated' % len(pool),
+                   'resets_in_timed_region': counts['resets'], 'stats_reads_in_timed_region': counts['stats_reads'],
+                   'timed_region_starts_at_episode_step': pos_timed,
+                   'launch': 'hip graph per run of steps between episode boundaries' if graphs else 'one host call per step',
+                   'graph_replays': counts['graph_replays'], 'eager_steps': counts['eager_steps'],
+                   'benchmark_info': has_info,
+                   'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
+                   'parallelism': 'env-sharded dp%d' % world_size, 'backend': backend if world_size > 1 else None},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': measured_traffic(name) if B == envs_per_gpu else None,
+                     'kernel': 'mpe env_step (fused)', 'algorithmic_bytes_per_launch': bytes_per_launch,
+                     'bytes_per_env_step': elems * esize,
+                     'avg_launch_ms': kern_ms, 'median_launch_ms': kern_med,
+                     'timing': ('hip events around each run of consecutive launches (one graph replay) / launches'
+                                if graphs else 'hip events around each run of consecutive launches / launches')
+                               if events else 'wall/steps'},
+        'episode_stats': summarize_stats(stats_total, n, EPISODE_LEN),
+        'episode_stats_vector': [float(x) for x in stats_total.cpu()],
+    }
+    del graphs, env, pool, stats
+    torch.cuda.empty_cache()
+    return out
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--workload', default='simple_tag_1M_f32', choices=sorted(WORKLOADS))
+    ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the multi-rank path '
+                         'with every rank on whatever GPUs exist (ranks then share devices)')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configs')
+    ap.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (roofline from wall time)')
+    ap.add_argument('--no-graph', action='store_true', help='one host call per step instead of HIP-graph replays')
+    ap.add_argument('--actions', default='random', choices=['random', 'by-env-id'],
+                    help='by-env-id: the action of an env depends on its global id only (sharding-invariant runs)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world_size = int(os.environ.get('WORLD_SIZE', 1))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world_size
+
+    cpu = None
+    if world_size == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_baseline_seconds)       # forks workers: before anything touches the GPU
+
+    dev_index = local_rank if args.backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    import torch.distributed as dist
+    if world_size > 1:
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
+
+    out = run_workload(args.workload, args.steps, args.warmup, args.envs, device, rank, world_size, dist, args.backend,
+                       use_graph=not args.no_graph, use_events=not args.no_events, actions=args.actions)
     if rank == 0:
-        value = B * world_size * n * args.steps / elapsed
-        out = {
-            'metric': 'agent-steps/sec (whole node) for batched simple_tag' if scenario == 'simple_tag' and not kwargs
-                      else 'agent-steps/sec (whole node), %s' % args.workload,
-            'value': value, 'unit': 'agent-steps/s', 'n_gpus': world_size, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if dtype == torch.float32 else 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'scenario': scenario, 'envs_per_gpu': B, 'row_stride': env.world.ld,
-                       'agents': n, 'entities': len(env.world.entities), 'episode_len': EPISODE_LEN,
-                       'actions': 'softmax(N(0,1)) soft one-hot, %d resident buffers rotated' % len(pool),
-                       'reset_in_timed_region': True, 'benchmark_info': has_info,
-                       'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
-                       'parallelism': 'env-sharded dp%d' % world_size, 'backend': args.backend if world_size > 1 else None},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': measured_traffic(args.workload) if B == envs_per_gpu else None,
-                         'kernel': 'mpe env_step (fused)', 'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'bytes_per_env_step': elems * env.world.pos.element_size(),
-                         'avg_launch_ms': kern_ms, 'median_launch_ms': kern_med,
-                         'timing': 'hip events around each episode segment of consecutive launches / launches' if events else 'wall/steps'},
-            'episode_stats': summarize_stats(stats_total, n, EPISODE_LEN),
-        }
-        if world_size == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_seconds)
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+        if (world_size == 1 and args.workload == 'simple_tag_1M_f32' and not args.envs and not args.no_other_configs):
+            out['other_configs'] = {}
+            for name, st, wu in OTHER_CONFIGS:
+                r = run_workload(name, st, wu, 0, device, 0, 1, dist, args.backend, use_graph=not args.no_graph,
+                                 use_events=not args.no_events)
+                out['other_configs'][name] = {k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype',
+                                                                 'config', 'roofline')}
         print(json.dumps(out))
     if world_size > 1:
         dist.destroy_process_group()
