@@ -132,7 +132,9 @@ typedef struct mpe_scenario_desc {
   int8_t forced_id[MPE_MAX_AGENTS];  /* >= 0: is commanded; -1: none                            */
   uint8_t advleader[MPE_MAX_AGENTS];
   uint8_t advsuperleader[MPE_MAX_AGENTS]; /* its command is the raw c[0:2], observed not applied
-                                             (core.py:162-163)                                  */
+                                             (core.py:162-163).  A force_id shared by a super-leader and a
+                                             plain leader is refused (MPE_ERR_UNSUPPORTED): the reference
+                                             aliases the super-leader's action.c there (core.py:163,192)  */
   int32_t reward_variant;            /* 0: L1F.. / S1L.. default; 1: S1L2F2_10Targets_wide_rewardFixed;
                                         MPE_HIER_MOVING: 0 = L1F4_MovingTarget, 1 = S1L2F4_MovingTarget   */
   int32_t n_target_obs;              /* target_pos[0:n] in the observation (3)                  */

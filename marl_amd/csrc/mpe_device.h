@@ -338,10 +338,22 @@ __device__ __forceinline__ bool kind_is_comm(int kind) {
   return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE;
 }
 
-// is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): strict <.
+// is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): sqrt(dx^2 + dy^2) < dmin, strict.
 template <typename T>
 __device__ __forceinline__ bool touching(T dx, T dy, T dmin) {
   return t_sqrt<T>(dx * dx + dy * dy) < dmin;
+}
+// f64: the same boolean without the ~25-instruction correctly rounded square root.  sqrt is monotonic, so away from
+// the threshold the squares decide: d2 < dmin^2 (1 - 2^-50) implies sqrt(d2) < dmin (1 - 2^-51.2), which rounds to a
+// double below dmin; d2 > dmin^2 (1 + 2^-50) likewise rounds to one >= dmin.  Inside that band (a few ulps; about one
+// contact test in 10^15) the reference's expression itself is evaluated.  NaN -> false both ways.
+template <>
+__device__ __forceinline__ bool touching<double>(double dx, double dy, double dmin) {
+  const double d2 = dx * dx + dy * dy, m2 = dmin * dmin;
+  const double lo = m2 * (1.0 - 0x1p-50), hi = m2 * (1.0 + 0x1p-50);
+  bool r = d2 < lo;
+  if (d2 >= lo && d2 <= hi) r = sqrt(d2) < dmin;
+  return r;
 }
 
 // bound() of simple_tag.agent_reward (simple_tag.py:103-108), x = |pos|.
@@ -355,7 +367,10 @@ __device__ __forceinline__ T tag_bound(T x) {
 
 template <typename T>
 __device__ __forceinline__ T tag_bound_sel(T x) {
-  const T e = t_exp<T>(T(2) * x - T(2));
+  // f64: exp is ~45 instructions and only agents outside the arena (|pos| >= 1, or NaN) need it: skipped by a
+  // wavefront-level branch when no lane does; f32: one v_exp_f32, evaluated unconditionally
+  T e = T(0);
+  if (sizeof(T) == 4 || !(x < T(1.0))) e = t_exp<T>(T(2) * x - T(2));
   const T hi = T(10) < e ? T(10) : e;
   const T mid = (x - T(0.9)) * T(10);
   return x < T(0.9) ? T(0) : (x < T(1.0) ? mid : hi);

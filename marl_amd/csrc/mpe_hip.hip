@@ -150,6 +150,14 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
     // a super-leader's command is c[0:2] (core.py:163)
     if (h->advsuperleader[a] && h->force_id[a] >= 0 && !h->silent[a] && h->dim_c < 2) return MPE_ERR_DESC;
   }
+  // core.py:163 makes agent.leader_force an ALIAS of the super-leader's action.c[0:2]; a plain leader with the same
+  // force_id then adds its push into that array in place (core.py:192), changing the super-leader's own command for
+  // every later agent and its state.c.  No scenario file of the reference shares a force_id between a super-leader
+  // and a plain leader; a world that does is refused rather than run with different semantics.
+  for (int a = 0; a < h->n_agents; ++a)
+    for (int b = 0; b < h->n_agents; ++b)
+      if (h->force_id[a] >= 0 && h->force_id[a] == h->force_id[b] && h->advsuperleader[a] && !h->advsuperleader[b])
+        return MPE_ERR_UNSUPPORTED;
   if (h->kind == MPE_HIER_PURSUIT) {
     if (h->n_target_obs < 0 || h->n_target_obs > MPE_MAX_ENTITIES) return MPE_ERR_DESC;
     if (h->reward_variant != 0 && h->reward_variant != 1) return MPE_ERR_DESC;

@@ -31,9 +31,15 @@ namespace mpe {
 // (1024-lane workgroups, +3.5 % when uncapped, need 4 waves/SIMD and lose to this: dropped.)
 // simple.py's world moves 20 elements per env step, not 126: it wants every wavefront it can get
 // (5866 GB/s uncapped, 4803 capped at 3).
-constexpr int small_wave_cap(int kind) { return kind == MPE_SIMPLE ? 8 : 3; }
+// f64 simple_tag is the exception the other way: its ~3 200 f64 instructions per wavefront (~120 us of VALU time at
+// 1 Mi envs) weigh about as much as its 1 GB of traffic (~160 us), so it wants every wavefront the registers allow to
+// overlap the two: 207.7 us capped at 3, 212.0 at 4, 197.4 at 5, 197.2 uncapped (r2, MI355X).  f64 simple_spread
+// (65 536 envs = one wavefront per SIMD) is indifferent: 11.7 us at 3 or 4, 12.2 at 5.
+constexpr int small_wave_cap(int kind, int elem_bytes) {
+  return kind == MPE_SIMPLE ? 8 : (kind == MPE_SIMPLE_TAG && elem_bytes == 8 ? 5 : 3);
+}
 #ifndef MPE_SMALL_ATTR
-#define MPE_SMALL_ATTR __attribute__((amdgpu_waves_per_eu(1, small_wave_cap(KIND))))
+#define MPE_SMALL_ATTR __attribute__((amdgpu_waves_per_eu(1, small_wave_cap(KIND, (int)sizeof(T)))))
 #endif
 
 template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>

@@ -109,6 +109,17 @@ class ScenarioSpec:
         if self.advfollower is None:                 # L1F2_3Targets_100observe.py:40,52,64: the silent adversaries
             self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind in (HIER_PURSUIT, HIER_MOVING)
                                 for i in range(A)]
+        self.check_no_alias()
+
+    def check_no_alias(self):
+        """core.py:163 aliases the super-leader's action.c[0:2]; a plain leader with the same force_id would mutate it
+        in place (core.py:192).  Not restated (no reference scenario does it): refused, like mpe_desc_check."""
+        for a in range(self.n_agents):
+            for b in range(self.n_agents):
+                if (self.force_id[a] >= 0 and self.force_id[a] == self.force_id[b]
+                        and self.advsuperleader[a] and not self.advsuperleader[b]):
+                    raise ValueError('a super-leader and a plain leader share force_id %d (core.py:163,192 aliasing)'
+                                     % self.force_id[a])
 
     def act_dim(self, i):
         """environment.py:42-76: Discrete(5) for silent agents, MultiDiscrete([0,4],[0,dim_c-1]) otherwise."""
@@ -410,6 +421,10 @@ class SerialEnv:
                 if leader.force_id < 0 or agent.forced_id != leader.force_id:
                     continue
                 if leader.advsuperleader:          # observed only; NOT added to the physical force
+                    # The reference assigns the VIEW leader.action.c[0:2] (core.py:163): a plain leader with the same
+                    # force_id would then add its push into the super-leader's own action.c (core.py:192).  No
+                    # reference scenario shares a force_id that way; ScenarioSpec refuses it (check_no_alias) and so
+                    # does mpe_desc_check (MPE_ERR_UNSUPPORTED), so a copy is equivalent here.
                     agent.leader_force = np.array(leader.c_act[0:2], dtype=np.float64)
                 else:
                     cmd = int(np.argmax(np.array(leader.c_act)))

@@ -481,8 +481,27 @@ def main():
         save('m_' + name, **rollout_hier(name, range(24), 25, actions='softmax'))
         save('m_' + name + '_dense', **rollout_hier(name, range(24), 25, init=dense_init))
         save('m_' + name + '_crowd', **rollout_hier(name, range(16), 6, init=crowd_init))
+    hier_rest()
     kat_cases()
 
 
+# The nine hierarchy files that round 1 covered only through hierarchy.PRESETS (they differ from the files above in
+# counts, zoom rate and observation radius): short fixtures, enough to pin the world constants read back from the
+# reference's make_world() and a few steps of the dynamics, rewards and masked / sorted observations.
+HIER_REST = (('L1F2_10Targets_wide', 8, 25), ('S1L1F1_10Targets_wide', 8, 25),
+             ('L1F2_3Targets_090observe', 4, 5), ('L1F2_3Targets_095observe', 4, 5), ('L1F2_3Targets_105observe', 4, 5),
+             ('S1L2F2_3Targets_075observe', 4, 5), ('S1L2F2_3Targets_090observe', 4, 5),
+             ('S1L2F2_3Targets_095observe', 4, 5), ('S1L2F2_3Targets_105observe', 4, 5))
+
+
+def hier_rest():
+    for name, n, T in HIER_REST:
+        save('h_' + name, **rollout_hier(name, range(n), T, actions='softmax'))
+        save('h_' + name + '_dense', **rollout_hier(name, range(max(2, n // 2)), T, init=dense_init))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'hier_rest':     # only the fixtures added in round 2
+        hier_rest()
+    else:
+        main()

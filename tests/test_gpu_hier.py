@@ -24,7 +24,11 @@ if torch.cuda.is_available():
 F64_TOL = 1e-9
 BASES = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
          'L1F1_10Targets_wide', 'L1F4_3Targets_wide', 'S1L2F2_10Targets_wide',
-         'S1L2F2_10Targets_wide_rewardFixed']
+         'S1L2F2_10Targets_wide_rewardFixed',
+         # round 2: the remaining files (HIER_3_10_2 / HIER_3_10_1 register kernels, the other zoom rates)
+         'L1F2_10Targets_wide', 'S1L1F1_10Targets_wide', 'L1F2_3Targets_090observe', 'L1F2_3Targets_095observe',
+         'L1F2_3Targets_105observe', 'S1L2F2_3Targets_075observe', 'S1L2F2_3Targets_090observe',
+         'S1L2F2_3Targets_095observe', 'S1L2F2_3Targets_105observe']
 # the two *_MovingTarget files (kind MPE_HIER_MOVING): a moving prey instead of landmarks
 MOVING = ['L1F4_MovingTarget', 'S1L2F4_MovingTarget']
 HIER_CASES = (['h_' + b + suf for b in BASES for suf in ('', '_dense')]

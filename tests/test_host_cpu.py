@@ -150,7 +150,11 @@ def test_spaces_and_scenario_loader():
 
 GOLDEN_HIER = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
                'L1F1_10Targets_wide', 'L1F4_3Targets_wide', 'S1L2F2_10Targets_wide',
-               'S1L2F2_10Targets_wide_rewardFixed', 'L1F4_MovingTarget', 'S1L2F4_MovingTarget']
+               'S1L2F2_10Targets_wide_rewardFixed', 'L1F4_MovingTarget', 'S1L2F4_MovingTarget',
+               # round 2: the other nine files -- every one of the reference's 18 scenario files now has a fixture
+               'L1F2_10Targets_wide', 'S1L1F1_10Targets_wide', 'L1F2_3Targets_090observe', 'L1F2_3Targets_095observe',
+               'L1F2_3Targets_105observe', 'S1L2F2_3Targets_075observe', 'S1L2F2_3Targets_090observe',
+               'S1L2F2_3Targets_095observe', 'S1L2F2_3Targets_105observe']
 
 
 @pytest.mark.parametrize('name', GOLDEN_HIER)
@@ -183,7 +187,7 @@ def test_hierarchy_presets_cover_every_reference_file():
     import glob
     live = sorted(os.path.basename(f)[:-3] for f in glob.glob('/root/reference/multiagent-particle-envs/multiagent/scenarios/[LS]*.py'))
     assert not live or live == sorted(ref)                  # the reference tree exists in the build container only
-    assert sorted(hierarchy.PRESETS) == sorted(ref)
+    assert sorted(hierarchy.PRESETS) == sorted(ref) == sorted(GOLDEN_HIER)   # one reference-generated fixture per file
     for name in ref:
         sc = hierarchy.bound_module(name).Scenario()
         sc._finish_world = lambda world: world
@@ -340,3 +344,22 @@ def test_integration_md_stub_matches_the_library():
     exec(src[src.index('class Buffers'):src.index('lib.mpe_env_step_f32.argtypes')], ns)
     assert [n for n, _ in ns['Buffers']._fields_] == [n for n, _ in _hip.Buffers._fields_]
     assert 'mpe_abi_version() == %d' % _hip.ABI_VERSION in src
+
+
+def test_shared_force_id_between_super_leader_and_leader_is_refused():
+    """core.py:163 makes agent.leader_force an alias of the super-leader's action.c[0:2]; a plain leader with the
+    same force_id then mutates it in place (core.py:192).  No reference scenario does that; neither the oracle nor
+    the library restates it: both refuse such a world instead of running it with other semantics."""
+    import dataclasses
+    from marl_amd import _hip
+    spec = _hier_spec('h_S1L2F2_3Targets_100observe')
+    sup = spec.advsuperleader.index(True)
+    plain = [i for i in range(spec.n_agents) if spec.force_id[i] >= 0 and not spec.advsuperleader[i]][0]
+    d = _desc(spec)
+    assert _hip.lib.mpe_desc_check(d) == 0
+    d.force_id[plain] = d.force_id[sup]
+    assert _hip.lib.mpe_desc_check(d) == -5
+    fid = list(spec.force_id)
+    fid[plain] = fid[sup]
+    with pytest.raises(ValueError):
+        dataclasses.replace(spec, force_id=fid)

@@ -102,6 +102,15 @@ HIER_CASES = ['h_L1F2_3Targets_100observe', 'h_L1F2_3Targets_100observe_dense',
               'h_L1F4_3Targets_wide', 'h_L1F4_3Targets_wide_dense',
               'h_S1L2F2_10Targets_wide', 'h_S1L2F2_10Targets_wide_dense',
               'h_S1L2F2_10Targets_wide_rewardFixed', 'h_S1L2F2_10Targets_wide_rewardFixed_dense',
+              'h_L1F2_10Targets_wide', 'h_L1F2_10Targets_wide_dense',
+              'h_S1L1F1_10Targets_wide', 'h_S1L1F1_10Targets_wide_dense',
+              'h_L1F2_3Targets_090observe', 'h_L1F2_3Targets_090observe_dense',
+              'h_L1F2_3Targets_095observe', 'h_L1F2_3Targets_095observe_dense',
+              'h_L1F2_3Targets_105observe', 'h_L1F2_3Targets_105observe_dense',
+              'h_S1L2F2_3Targets_075observe', 'h_S1L2F2_3Targets_075observe_dense',
+              'h_S1L2F2_3Targets_090observe', 'h_S1L2F2_3Targets_090observe_dense',
+              'h_S1L2F2_3Targets_095observe', 'h_S1L2F2_3Targets_095observe_dense',
+              'h_S1L2F2_3Targets_105observe', 'h_S1L2F2_3Targets_105observe_dense',
               # the *_MovingTarget files: a moving prey instead of landmarks, own observation / reward text
               'm_L1F4_MovingTarget', 'm_L1F4_MovingTarget_dense', 'm_L1F4_MovingTarget_crowd',
               'm_S1L2F4_MovingTarget', 'm_S1L2F4_MovingTarget_dense', 'm_S1L2F4_MovingTarget_crowd']
