@@ -317,6 +317,16 @@ int mpe_replay_add_f32(int64_t capacity, int64_t next_idx, int64_t n, int width,
                        const mpe_replay_seg *segs, void *ring, void *stream);
 int mpe_replay_add_f64(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,
                        const mpe_replay_seg *segs, void *ring, void *stream);
+/* The same append for several buffers (one per agent: maddpg.py:147,154-156) in ONE launch: n transitions go into
+ * every job's ring, each from its own segments.  Equal to n_jobs mpe_replay_add calls. */
+typedef struct mpe_replay_job {
+  int64_t capacity, next_idx;
+  int32_t width, nseg;
+  const mpe_replay_seg *segs;
+  void *ring;
+} mpe_replay_job;
+int mpe_replay_add_multi_f32(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream);
+int mpe_replay_add_multi_f64(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream);
 int mpe_replay_gather_f32(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
                           void *out, void *stream);
 int mpe_replay_gather_f64(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
@@ -339,6 +349,18 @@ int mpe_replay_gather_f64(int64_t capacity, int width, const int64_t *idx, int64
 int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0, int s1, const void *obs,
                           const void *weights, const void *u, uint64_t seed, uint32_t call_counter, uint64_t env_id0,
                           void *act, void *stream);
+
+/* Every agent's actor in ONE launch (the reference loops over trainers, experiments/simple_train.py:260): job i reads
+ * its own observation rows / weights / uniforms and writes its own action rows; B, the row strides, call_counter and
+ * env_id0 are shared; job.seed keys the agent's Philox stream.  Equal to n_jobs mpe_actor_forward_f32 calls. */
+typedef struct mpe_actor_job {
+  const void *obs, *weights, *u;
+  void *act;
+  int32_t in_dim, s0, s1;
+  uint64_t seed;
+} mpe_actor_job;
+int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs, int64_t ld_act,
+                                uint32_t call_counter, uint64_t env_id0, void *stream);
 
 /*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,

@@ -85,6 +85,18 @@ class ReplaySeg(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('rows', C.c_int32), ('row_stride', C.c_int64), ('env_stride', C.c_int64)]
 
 
+class ReplayJob(C.Structure):
+    """mpe_replay_job (include/mpe_hip.h): one buffer's share of a multi-buffer append."""
+    _fields_ = [('capacity', C.c_int64), ('next_idx', C.c_int64), ('width', C.c_int32), ('nseg', C.c_int32),
+                ('segs', C.POINTER(ReplaySeg)), ('ring', C.c_void_p)]
+
+
+class ActorJob(C.Structure):
+    """mpe_actor_job (include/mpe_hip.h): one agent's share of a multi-agent actor launch."""
+    _fields_ = [('obs', C.c_void_p), ('weights', C.c_void_p), ('u', C.c_void_p), ('act', C.c_void_p),
+                ('in_dim', C.c_int32), ('s0', C.c_int32), ('s1', C.c_int32), ('seed', C.c_uint64)]
+
+
 class MpeError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -123,11 +135,16 @@ def _load():
         f.restype, f.argtypes = ci, [dp, i64, i64, ci, ci, ci, C.c_double, vp, vp, vp, vp]
         f = getattr(L, 'mpe_replay_add_' + suf)       # capacity, next_idx, n, width, nseg, segs, ring, stream
         f.restype, f.argtypes = ci, [i64, i64, i64, ci, ci, C.POINTER(ReplaySeg), vp, vp]
+        f = getattr(L, 'mpe_replay_add_multi_' + suf)  # n_jobs, jobs, n, stream
+        f.restype, f.argtypes = ci, [ci, C.POINTER(ReplayJob), i64, vp]
         f = getattr(L, 'mpe_replay_gather_' + suf)    # capacity, width, idx, batch, ring, out, stream
         f.restype, f.argtypes = ci, [i64, ci, vp, i64, vp, vp, vp]
     # B, ld_obs, ld_act, in_dim, s0, s1, obs, weights, u, seed, call_counter, env_id0, act, stream
     L.mpe_actor_forward_f32.restype = ci
     L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]
+    # n_jobs, jobs, B, ld_obs, ld_act, call_counter, env_id0, stream
+    L.mpe_actor_forward_multi_f32.restype = ci
+    L.mpe_actor_forward_multi_f32.argtypes = [ci, C.POINTER(ActorJob), i64, i64, i64, u32, u64, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci, u32]
     L.mpe_stats_reduce.restype = ci

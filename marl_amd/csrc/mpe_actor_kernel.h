@@ -28,12 +28,28 @@ constexpr int kActorMaxOut = 16;
 // min 2^-24, max 1 - 2^-24.
 __device__ __forceinline__ float philox_open01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
-template <int O>  // output columns evaluated: 8 or 16 (>= s0 + s1); W3t / b3 keep their 16-column packing
-__global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0,
-                                                            int s1, const float *__restrict__ obs,
-                                                            const float *__restrict__ wts, const float *__restrict__ u,
-                                                            uint32_t k0, uint32_t k1, uint32_t counter, uint64_t env_id0,
-                                                            float *__restrict__ act) {
+// One agent's actor evaluation: where its observation rows, packed weights, optional uniforms and action rows are.
+struct ActorJob {
+  const float *obs, *wts, *u;
+  float *act;
+  int32_t in_dim, s0, s1;
+  uint32_t k0, k1;  // Philox key = the agent's seed
+};
+constexpr int kActorMaxJobs = 16;  // agents per launch (blockIdx.y); more agents = more launches
+struct ActorJobs {
+  ActorJob j[kActorMaxJobs];
+};
+
+template <int O>  // output columns evaluated: 8 or 16 (>= s0 + s1 of every job); W3t / b3 keep their 16-column packing
+__global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64_t B, int64_t ld_obs, int64_t ld_act,
+                                                                           const ActorJobs jobs, uint32_t counter,
+                                                                           uint64_t env_id0) {
+  // blockIdx.y = agent: every agent of the step in ONE launch (wave-uniform job fields -> scalar loads)
+  const ActorJob &job = jobs.j[blockIdx.y];
+  const float *__restrict__ obs = job.obs, *__restrict__ wts = job.wts, *__restrict__ u = job.u;
+  float *__restrict__ act = job.act;
+  const int in_dim = job.in_dim, s0 = job.s0, s1 = job.s1;
+  const uint32_t k0 = job.k0, k1 = job.k1;
   constexpr int H = kActorHidden, OP = kActorMaxOut;
   const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = env < B;

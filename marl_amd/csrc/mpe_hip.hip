@@ -779,6 +779,61 @@ __global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, 
   }
 }
 
+// The same append for several replay buffers in one launch (blockIdx.y = buffer): one per agent and step in the
+// reference's loop (experiments/simple_train.py:284-287).  Flat TW = 256 form only; the host falls back to one launch
+// per buffer for shapes it does not cover.
+constexpr int kReplayMaxJobs = 8;
+template <typename T>
+struct ReplayJobs {
+  ReplaySegs sg[kReplayMaxJobs];
+  int64_t capacity[kReplayMaxJobs], next_idx[kReplayMaxJobs], skip[kReplayMaxJobs];
+  T *ring[kReplayMaxJobs];
+  int32_t width[kReplayMaxJobs];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void replay_add_multi_kernel(int64_t n, const ReplayJobs<T> jobs) {
+  extern __shared__ __align__(16) unsigned char replay_lds[];
+  constexpr int TW = 256, LDT = TW + 1;
+  T *tile = reinterpret_cast<T *>(replay_lds);
+  const int jb = blockIdx.y;
+  const ReplaySegs &sg = jobs.sg[jb];
+  const int width = jobs.width[jb];
+  const int64_t capacity = jobs.capacity[jb];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t e0 = jobs.skip[jb] + (int64_t)blockIdx.x * TW;
+  if (e0 >= n) return;  // workgroup-uniform: this buffer keeps fewer transitions than the widest job
+  const int ne = (int)(n - e0 < TW ? n - e0 : TW);
+  constexpr int kU = 10;
+  const int el = 64 * w + lane;
+  for (int c0 = 0; c0 < width; c0 += kU) {
+    T v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int c = c0 + u;
+      v[u] = T(0);
+      if (c < width && el < ne) {
+        int s = 0;
+        while (c >= sg.row0[s + 1]) ++s;
+        const T *src = (const T *)sg.ptr[s];
+        v[u] = ld_stream(src + (int64_t)(c - sg.row0[s]) * sg.row_stride[s] + (e0 + el) * sg.env_stride[s]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (c0 + u < width) tile[(c0 + u) * LDT + el] = v[u];
+  }
+  __syncthreads();
+  const int total = ne * width;
+  T *ring = jobs.ring[jb];
+  const int64_t r0 = (jobs.next_idx[jb] + e0) % capacity;
+  for (int f = threadIdx.x; f < total; f += 256) {
+    const int e = f / width, c = f - e * width;
+    int64_t r = r0 + e;
+    r = r >= capacity ? r - capacity : r;
+    st_stream(ring + r * width + c, tile[c * LDT + e]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void replay_gather_kernel(int64_t capacity, int width, const int64_t *idx,
                                                              int64_t total, const T *ring, T *out) {
@@ -857,6 +912,78 @@ static int replay_add_impl(int64_t capacity, int64_t next_idx, int64_t n, int wi
   return (int)hipGetLastError();
 }
 
+// Fills the kernel-side segment table of one append from the C ABI's segments; returns the record width or an error.
+template <typename T>
+static int replay_bind_segs(int nseg, const mpe_replay_seg *segs, ReplaySegs &sg) {
+  if (!segs) return MPE_ERR_NULL;
+  if (nseg < 1 || nseg > 8) return MPE_ERR_ARG;
+  int rows = 0;
+  for (int s = 0; s < nseg; ++s) {
+    if (!segs[s].ptr) return MPE_ERR_NULL;
+    if (segs[s].rows < 1) return MPE_ERR_ARG;
+    if (misaligned<T>(segs[s].ptr)) return MPE_ERR_ALIGN;
+    sg.ptr[s] = segs[s].ptr;
+    sg.row_stride[s] = segs[s].row_stride;
+    sg.env_stride[s] = segs[s].env_stride;
+    sg.row0[s] = rows;
+    rows += segs[s].rows;
+  }
+  for (int s = nseg; s <= 8; ++s) sg.row0[s] = rows;
+  sg.nseg = nseg;
+  return rows;
+}
+
+template <typename T>
+static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream) {
+  if (!jobs) return MPE_ERR_NULL;
+  if (n_jobs < 1 || n < 0) return MPE_ERR_ARG;
+  for (int i = 0; i < n_jobs; ++i) {  // validate everything before the first launch
+    const mpe_replay_job &j = jobs[i];
+    ReplaySegs sg{};
+    const int rows = replay_bind_segs<T>(j.nseg, j.segs, sg);
+    if (rows < 0) return rows;
+    if (!j.ring) return MPE_ERR_NULL;
+    if (j.capacity < 1 || j.next_idx < 0 || j.next_idx >= j.capacity || rows != j.width) return MPE_ERR_ARG;
+    if (misaligned<T>(j.ring)) return MPE_ERR_ALIGN;
+  }
+  if (n == 0) return MPE_OK;
+  int i0 = 0;
+  while (i0 < n_jobs) {
+    // a run of jobs the one-launch kernel covers (records of <= kReplayFlatCols columns, tile in 64 KiB of LDS, a
+    // full 256-transition tile to store); anything else goes through the single-buffer entry point
+    ReplayJobs<T> tab{};
+    int nj = 0, wmax = 0;
+    int64_t keep_max = 0;
+    while (i0 + nj < n_jobs && nj < kReplayMaxJobs) {
+      const mpe_replay_job &j = jobs[i0 + nj];
+      const int64_t skip = n > j.capacity ? n - j.capacity : 0;
+      if (j.width > kReplayFlatCols || (size_t)j.width * 257 * sizeof(T) > 64 * 1024 || n - skip < 256) break;
+      replay_bind_segs<T>(j.nseg, j.segs, tab.sg[nj]);
+      tab.capacity[nj] = j.capacity;
+      tab.next_idx[nj] = j.next_idx;
+      tab.skip[nj] = skip;
+      tab.ring[nj] = (T *)j.ring;
+      tab.width[nj] = j.width;
+      wmax = j.width > wmax ? j.width : wmax;
+      keep_max = n - skip > keep_max ? n - skip : keep_max;
+      ++nj;
+    }
+    if (nj == 0) {
+      const mpe_replay_job &j = jobs[i0];
+      const int rc = replay_add_impl<T>(j.capacity, j.next_idx, n, j.width, j.nseg, j.segs, j.ring, stream);
+      if (rc) return rc;
+      ++i0;
+      continue;
+    }
+    const dim3 grid((unsigned)((keep_max + 255) / 256), (unsigned)nj), block(256);
+    hipLaunchKernelGGL(replay_add_multi_kernel<T>, grid, block, (size_t)wmax * 257 * sizeof(T), (hipStream_t)stream, n, tab);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    i0 += nj;
+  }
+  return MPE_OK;
+}
+
 template <typename T>
 static int replay_gather_impl(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
                               void *out, void *stream) {
@@ -871,20 +998,47 @@ static int replay_gather_impl(int64_t capacity, int width, const int64_t *idx, i
   return (int)hipGetLastError();
 }
 
+static int actor_job_check(const mpe_actor_job *j) {
+  if (!j->obs || !j->weights || !j->act) return MPE_ERR_NULL;
+  if (j->in_dim < 1 || j->in_dim > 4096 || j->s0 < 1 || j->s1 < 0 || j->s0 + j->s1 > kActorMaxOut) return MPE_ERR_ARG;
+  if (misaligned<float>(j->obs) || misaligned<float>(j->weights) || misaligned<float>(j->u) || misaligned<float>(j->act))
+    return MPE_ERR_ALIGN;
+  return MPE_OK;
+}
+
+extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs,
+                                           int64_t ld_act, uint32_t call_counter, uint64_t env_id0, void *stream) {
+  if (!jobs) return MPE_ERR_NULL;
+  if (n_jobs < 1) return MPE_ERR_ARG;
+  if (B < 1 || ld_obs < B || ld_act < B) return MPE_ERR_BATCH;
+  for (int i = 0; i < n_jobs; ++i) {
+    const int rc = actor_job_check(&jobs[i]);
+    if (rc) return rc;
+  }
+  for (int i0 = 0; i0 < n_jobs; i0 += kActorMaxJobs) {  // kActorMaxJobs agents per launch
+    const int nj = n_jobs - i0 < kActorMaxJobs ? n_jobs - i0 : kActorMaxJobs;
+    ActorJobs tab{};
+    int wide = 0;
+    for (int i = 0; i < nj; ++i) {
+      const mpe_actor_job &j = jobs[i0 + i];
+      tab.j[i] = ActorJob{(const float *)j.obs, (const float *)j.weights, (const float *)j.u, (float *)j.act,
+                          j.in_dim, j.s0, j.s1, (uint32_t)j.seed, (uint32_t)(j.seed >> 32)};
+      wide = wide || j.s0 + j.s1 > 8;
+    }
+    const dim3 grid((unsigned)((B + 255) / 256), (unsigned)nj), block(256);
+    auto kern = wide ? actor_forward_kernel<16> : actor_forward_kernel<8>;
+    hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, tab, call_counter, env_id0);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return MPE_OK;
+}
+
 extern "C" int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0, int s1,
                                      const void *obs, const void *weights, const void *u, uint64_t seed,
                                      uint32_t call_counter, uint64_t env_id0, void *act, void *stream) {
-  if (!obs || !weights || !act) return MPE_ERR_NULL;
-  if (B < 1 || ld_obs < B || ld_act < B) return MPE_ERR_BATCH;
-  if (in_dim < 1 || in_dim > 4096 || s0 < 1 || s1 < 0 || s0 + s1 > kActorMaxOut) return MPE_ERR_ARG;
-  if (misaligned<float>(obs) || misaligned<float>(weights) || misaligned<float>(u) || misaligned<float>(act))
-    return MPE_ERR_ALIGN;
-  const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-  auto kern = s0 + s1 <= 8 ? actor_forward_kernel<8> : actor_forward_kernel<16>;
-  hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, in_dim, s0, s1,
-                     (const float *)obs, (const float *)weights, (const float *)u, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), call_counter, env_id0, (float *)act);
-  return (int)hipGetLastError();
+  const mpe_actor_job job = {obs, weights, u, act, in_dim, s0, s1, seed};
+  return mpe_actor_forward_multi_f32(1, &job, B, ld_obs, ld_act, call_counter, env_id0, stream);
 }
 
 // One workgroup per column; rows are summed in a fixed order (thread t takes rows t, t+256, ...
@@ -1000,6 +1154,9 @@ extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, 
   extern "C" int mpe_replay_add_##SUF(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,      \
                                       const mpe_replay_seg *segs, void *ring, void *stream) {                  \
     return replay_add_impl<T>(capacity, next_idx, n, width, nseg, segs, ring, stream);                         \
+  }                                                                                                            \
+  extern "C" int mpe_replay_add_multi_##SUF(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream) { \
+    return replay_add_multi_impl<T>(n_jobs, jobs, n, stream);                                                  \
   }                                                                                                            \
   extern "C" int mpe_replay_gather_##SUF(int64_t capacity, int width, const int64_t *idx, int64_t batch,       \
                                          const void *ring, void *out, void *stream) {                          \

@@ -94,6 +94,40 @@ def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0)
     return act[:, :B].t()
 
 
+@torch.no_grad()
+def act_all(trainers, obs_n):
+    """``[tr.action(obs) for tr, obs in zip(trainers, obs_n)]`` (experiments/simple_train.py:260) with every agent's
+    network + Gumbel-softmax sample in ONE launch (libmpe_hip.so: mpe_actor_forward_multi_f32).  Falls back to the
+    per-agent calls when some agent's observation / model is not what the fused kernel takes."""
+    from . import _hip
+    jobs, outs = [], []
+    B = ld = None
+    for tr, obs in zip(trainers, obs_n):
+        sizes = tr.sizes_n[tr.agent_index]
+        ok = (obs.dim() == 2 and obs.dtype == torch.float32 and obs.is_cuda and obs.stride(0) == 1 and obs.shape[1] > 1
+              and len(sizes) <= 2 and sum(sizes) <= ACTOR_MAX_OUT and (B is None or (obs.shape[0], obs.stride(1)) == (B, ld)))
+        if ok and tr._packed is None:
+            tr._packed = pack_actor(tr.p)
+        if not ok or tr._packed is None:
+            return [t.action(o) for t, o in zip(trainers, obs_n)]
+        B, ld = obs.shape[0], obs.stride(1)
+        act = torch.empty(sum(sizes), ld, dtype=torch.float32, device=obs.device)
+        outs.append(act[:, :B].t())
+        jobs.append(_hip.ActorJob(obs.data_ptr(), tr._packed.data_ptr(), None, act.data_ptr(), obs.shape[1], sizes[0],
+                                  sizes[1] if len(sizes) > 1 else 0, tr.seed))
+    t0 = trainers[0]
+    if any(t._act_calls != t0._act_calls or t.env_id0 != t0.env_id0 for t in trainers):
+        return [t.action(o) for t, o in zip(trainers, obs_n)]
+    for t in trainers:
+        t._act_calls += 1
+    arr = (_hip.ActorJob * len(jobs))(*jobs)
+    dev = obs_n[0].device
+    with _hip.on_device(dev):
+        _hip.check(_hip.lib.mpe_actor_forward_multi_f32(len(jobs), arr, B, ld, ld, t0._act_calls, t0.env_id0,
+                                                        _hip.stream_of(dev)), 'mpe_actor_forward_multi')
+    return outs
+
+
 def clip_by_norm_(params, clip_val):
     """tf_util.py:137-149: every variable's gradient clipped to norm clip_val on its own (tf.clip_by_norm)."""
     for p in params:

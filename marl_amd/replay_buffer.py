@@ -46,8 +46,8 @@ class ReplayBuffer(object):
             raise ValueError('expected %d transitions, got a tensor of shape %s' % (n, tuple(t.shape)))
         return t, _hip.ReplaySeg(t.data_ptr(), t.shape[1], t.stride(1), t.stride(0))
 
-    def add(self, obs_t, action, reward, obs_tp1, done):
-        """replay_buffer.py:25-32 for one step of B envs (= B add() calls in env order)."""
+    def _prepare(self, obs_t, action, reward, obs_tp1, done):
+        """Segment table of one append (allocates the ring on first use): (n, width, segment array, keep-alive)."""
         n = reward.shape[0]
         keep, segs = zip(*[self._seg(t, n) for t in (obs_t, action, reward, obs_tp1, done)])
         width = sum(s.rows for s in segs)
@@ -56,14 +56,21 @@ class ReplayBuffer(object):
             self._ring = torch.zeros(self._maxsize, width, dtype=self.dtype, device=self.device)
         elif (segs[0].rows, segs[1].rows) != self._dims or segs[3].rows != self._dims[0]:
             raise ValueError('transition shape changed: %s' % ((segs[0].rows, segs[1].rows),))
-        arr = (_hip.ReplaySeg * 5)(*segs)
+        return n, width, (_hip.ReplaySeg * 5)(*segs), keep
+
+    def _advance(self, n, keep):
+        self._keep = keep          # sources stay alive until the stream has consumed them
+        self._next_idx = (self._next_idx + n) % self._maxsize
+        self._len = min(self._len + n, self._maxsize)
+
+    def add(self, obs_t, action, reward, obs_tp1, done):
+        """replay_buffer.py:25-32 for one step of B envs (= B add() calls in env order)."""
+        n, width, arr, keep = self._prepare(obs_t, action, reward, obs_tp1, done)
         fn = getattr(_hip.lib, 'mpe_replay_add_' + _hip.suffix(self.dtype))
         with _hip.on_device(self.device):
             _hip.check(fn(self._maxsize, self._next_idx, n, width, 5, arr, self._ring.data_ptr(),
                           _hip.stream_of(self.device)), 'mpe_replay_add')
-        self._keep = keep          # sources stay alive until the stream has consumed them
-        self._next_idx = (self._next_idx + n) % self._maxsize
-        self._len = min(self._len + n, self._maxsize)
+        self._advance(n, keep)
 
     def _encode_sample(self, idxes):
         """replay_buffer.py:34-44: (obs [b, od], act [b, ad], rew [b], obs_next [b, od], done [b])."""
@@ -111,3 +118,22 @@ class ReplayBuffer(object):
 
     def collect(self):                  # :85-86
         return self.sample(-1)
+
+
+def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n):
+    """``buffers[i].add(obs_n[i], action_n[i], reward_n[i], obs_tp1_n[i], done_n[i])`` for every agent (the loop of
+    experiments/simple_train.py:284-287) in ONE launch (libmpe_hip.so: mpe_replay_add_multi_*)."""
+    b0 = buffers[0]
+    if any(b.device != b0.device or b.dtype != b0.dtype for b in buffers):
+        raise ValueError('add_all needs buffers on one device with one dtype')
+    prep = [b._prepare(*args) for b, args in zip(buffers, zip(obs_n, action_n, reward_n, obs_tp1_n, done_n))]
+    n = prep[0][0]
+    if any(p[0] != n for p in prep):
+        raise ValueError('every agent must add the same number of transitions')
+    jobs = (_hip.ReplayJob * len(buffers))(*[_hip.ReplayJob(b._maxsize, b._next_idx, p[1], 5, p[2], b._ring.data_ptr())
+                                             for b, p in zip(buffers, prep)])
+    fn = getattr(_hip.lib, 'mpe_replay_add_multi_' + _hip.suffix(b0.dtype))
+    with _hip.on_device(b0.device):
+        _hip.check(fn(len(buffers), jobs, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi')
+    for b, p in zip(buffers, prep):
+        b._advance(n, p[3])

@@ -256,3 +256,38 @@ def test_trainer_noise_follows_seed_and_global_env_id():
     hi = trainer(7, B).action(hi_rows[:, :B].t())
     assert torch.equal(whole[:B], lo) and torch.equal(whole[B:], hi)
     assert not torch.equal(whole, trainer(8, 0).action(obs_n[0]))         # the run seed matters
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scenario', ['simple_tag', 'S1L2F2_3Targets_100observe'])
+def test_act_all_and_add_all_equal_the_per_agent_calls(scenario):
+    """One launch for every agent's actor (mpe_actor_forward_multi_f32) and one for every agent's replay append
+    (mpe_replay_add_multi_f32) give exactly what the reference's per-trainer loops give (simple_train.py:260,284-287)."""
+    from marl_amd import make_env
+    from marl_amd.maddpg import MADDPGAgentTrainer, act_all
+    from marl_amd.replay_buffer import add_all
+    B = 3000
+    env = make_env(scenario, num_envs=B, dtype=torch.float32, seed=5)
+    shapes = [env.observation_space[i].shape for i in range(env.n)]
+
+    def trainers():
+        torch.manual_seed(1)
+        return [MADDPGAgentTrainer('a%d' % i, shapes, env.action_space, i, _args(), replay_size=4096, seed=9)
+                for i in range(env.n)]
+    one, many = trainers(), trainers()
+    obs_n = env.reset()
+    for step in range(3):                                  # 3 x 3000 transitions into rings of 4096: the last append wraps
+        a_many = act_all(many, obs_n)
+        a_one = [tr.action(o) for tr, o in zip(one, obs_n)]
+        for x, y in zip(a_many, a_one):
+            assert x.shape == y.shape and torch.equal(x, y)
+        new_obs_n, rew_n, done_n, _ = env.step(a_many)
+        add_all([tr.replay_buffer for tr in many], obs_n, a_many, rew_n, new_obs_n, done_n)
+        for i, tr in enumerate(one):
+            tr.experience(obs_n[i], a_one[i], rew_n[i], new_obs_n[i], done_n[i], False)
+        obs_n = new_obs_n
+    for t1, t2 in zip(one, many):
+        r1, r2 = t1.replay_buffer, t2.replay_buffer
+        assert len(r1) == len(r2) == 4096 and r1._next_idx == r2._next_idx == (3 * B) % 4096
+        assert torch.equal(r1._ring, r2._ring)
+    assert not torch.equal(a_many[0], act_all(many, obs_n)[0])          # the call counter moved on

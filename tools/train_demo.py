@@ -11,7 +11,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marl_amd import make_env  # noqa: E402
-from marl_amd.maddpg import MADDPGAgentTrainer  # noqa: E402
+from marl_amd.maddpg import MADDPGAgentTrainer, act_all  # noqa: E402
+from marl_amd.replay_buffer import add_all  # noqa: E402
 
 
 def main():
@@ -21,18 +22,17 @@ def main():
     args = types.SimpleNamespace(lr=1e-2, gamma=0.95, batch_size=1024, num_units=64, max_episode_len=25)
     env = make_env(scenario, num_envs=B, dtype=torch.float32, seed=0)
     obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
-    trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=1 << 22)
-                for i in range(env.n)]
+    trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=1 << 22,
+                                   seed=0, env_id0=env.world.env_id0) for i in range(env.n)]
     obs_n = env.reset()
     t0 = None
     for t in range(1, steps + 101):
         if t == 101:                                    # 100 warm-up steps, incl. the first update
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        action_n = [tr.action(obs) for tr, obs in zip(trainers, obs_n)]
+        action_n = act_all(trainers, obs_n)                    # every agent's actor: one launch
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
-        for i, tr in enumerate(trainers):
-            tr.experience(obs_n[i], action_n[i], rew_n[i], new_obs_n[i], done_n[i], t % 25 == 0)
+        add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n)   # one launch
         obs_n = new_obs_n
         if t % 25 == 0:
             obs_n = env.reset()
