@@ -95,37 +95,48 @@ def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0)
 
 
 @torch.no_grad()
-def act_all(trainers, obs_n):
+def act_all(trainers, obs_n, out=None):
     """``[tr.action(obs) for tr, obs in zip(trainers, obs_n)]`` (experiments/simple_train.py:260) with every agent's
     network + Gumbel-softmax sample in ONE launch (libmpe_hip.so: mpe_actor_forward_multi_f32).  Falls back to the
-    per-agent calls when some agent's observation / model is not what the fused kernel takes."""
+    per-agent calls when some agent's observation / model is not what the fused kernel takes.
+
+    ``out``: ``env.action_views`` -- the kernel then writes straight into the env's SoA action rows and ``env.step``
+    of the returned list copies nothing (without it each agent's action lands in a fresh buffer that ``env.step``
+    copies row-wise: 4 x 9 us per step for simple_tag at 1 Mi envs)."""
     from . import _hip
-    jobs, outs = [], []
-    B = ld = None
+    t0, o0 = trainers[0], obs_n[0]
+    fused = o0.dim() == 2 and o0.shape[1] > 1
+    B, ld = (o0.shape[0], o0.stride(1)) if fused else (0, 0)
     for tr, obs in zip(trainers, obs_n):
         sizes = tr.sizes_n[tr.agent_index]
-        ok = (obs.dim() == 2 and obs.dtype == torch.float32 and obs.is_cuda and obs.stride(0) == 1 and obs.shape[1] > 1
-              and len(sizes) <= 2 and sum(sizes) <= ACTOR_MAX_OUT and (B is None or (obs.shape[0], obs.stride(1)) == (B, ld)))
-        if ok and tr._packed is None:
+        fused = (fused and obs.dim() == 2 and obs.dtype == torch.float32 and obs.is_cuda and obs.stride(0) == 1
+                 and obs.shape[1] > 1 and (obs.shape[0], obs.stride(1)) == (B, ld) and len(sizes) <= 2
+                 and sum(sizes) <= ACTOR_MAX_OUT and tr._act_calls == t0._act_calls and tr.env_id0 == t0.env_id0)
+        if fused and tr._packed is None:
             tr._packed = pack_actor(tr.p)
-        if not ok or tr._packed is None:
-            return [t.action(o) for t, o in zip(trainers, obs_n)]
-        B, ld = obs.shape[0], obs.stride(1)
-        act = torch.empty(sum(sizes), ld, dtype=torch.float32, device=obs.device)
-        outs.append(act[:, :B].t())
-        jobs.append(_hip.ActorJob(obs.data_ptr(), tr._packed.data_ptr(), None, act.data_ptr(), obs.shape[1], sizes[0],
-                                  sizes[1] if len(sizes) > 1 else 0, tr.seed))
-    t0 = trainers[0]
-    if any(t._act_calls != t0._act_calls or t.env_id0 != t0.env_id0 for t in trainers):
-        return [t.action(o) for t, o in zip(trainers, obs_n)]
-    for t in trainers:
-        t._act_calls += 1
-    arr = (_hip.ActorJob * len(jobs))(*jobs)
-    dev = obs_n[0].device
-    with _hip.on_device(dev):
-        _hip.check(_hip.lib.mpe_actor_forward_multi_f32(len(jobs), arr, B, ld, ld, t0._act_calls, t0.env_id0,
-                                                        _hip.stream_of(dev)), 'mpe_actor_forward_multi')
-    return outs
+        fused = fused and tr._packed is not None
+    if not fused:
+        return [tr.action(obs) for tr, obs in zip(trainers, obs_n)]
+    nouts = [sum(tr.sizes_n[tr.agent_index]) for tr in trainers]
+    # action rows: the caller's SoA views when they share one row stride, else fresh buffers with the observations' stride
+    in_place = out is not None and len(out) == len(trainers) and all(
+        torch.is_tensor(v) and v.dim() == 2 and v.dtype == torch.float32 and v.device == o0.device
+        and tuple(v.shape) == (B, n) and v.stride(0) == 1 for v, n in zip(out, nouts))
+    strides = {v.stride(1) for v in out if v.shape[1] > 1} if in_place else set()
+    if in_place and len(strides) == 1:
+        acts, ld_act = list(out), strides.pop()
+    else:
+        acts, ld_act = [torch.empty(n, ld, dtype=torch.float32, device=o0.device)[:, :B].t() for n in nouts], ld
+    for tr in trainers:
+        tr._act_calls += 1
+    jobs = (_hip.ActorJob * len(trainers))(*[
+        _hip.ActorJob(obs.data_ptr(), tr._packed.data_ptr(), None, act.data_ptr(), obs.shape[1],
+                      tr.sizes_n[tr.agent_index][0], (tr.sizes_n[tr.agent_index] + [0])[1], tr.seed)
+        for tr, obs, act in zip(trainers, obs_n, acts)])
+    with _hip.on_device(o0.device):
+        _hip.check(_hip.lib.mpe_actor_forward_multi_f32(len(trainers), jobs, B, ld, ld_act, t0._act_calls, t0.env_id0,
+                                                        _hip.stream_of(o0.device)), 'mpe_actor_forward_multi')
+    return acts
 
 
 def clip_by_norm_(params, clip_val):

@@ -126,6 +126,10 @@ def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n):
     b0 = buffers[0]
     if any(b.device != b0.device or b.dtype != b0.dtype for b in buffers):
         raise ValueError('add_all needs buffers on one device with one dtype')
+    done_n = list(done_n)
+    if all(torch.is_tensor(d) and d is done_n[0] for d in done_n) and done_n[0].dtype != b0.dtype:
+        # env.step hands every agent the same bool tensor (environment.py:108): convert it once, not per buffer
+        done_n = [done_n[0].to(b0.dtype)] * len(done_n)
     prep = [b._prepare(*args) for b, args in zip(buffers, zip(obs_n, action_n, reward_n, obs_tp1_n, done_n))]
     n = prep[0][0]
     if any(p[0] != n for p in prep):

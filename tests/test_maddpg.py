@@ -291,3 +291,8 @@ def test_act_all_and_add_all_equal_the_per_agent_calls(scenario):
         assert len(r1) == len(r2) == 4096 and r1._next_idx == r2._next_idx == (3 * B) % 4096
         assert torch.equal(r1._ring, r2._ring)
     assert not torch.equal(a_many[0], act_all(many, obs_n)[0])          # the call counter moved on
+    # out=env.action_views: written in place, env.step then copies nothing, same values as a fresh buffer
+    a_ref = [x.clone() for x in act_all(trainers(), obs_n)]
+    a_in = act_all(trainers(), obs_n, out=env.action_views)
+    for x, y, v in zip(a_in, a_ref, env.action_views):
+        assert x.data_ptr() == v.data_ptr() and torch.equal(x, y)

@@ -30,7 +30,7 @@ def main():
         if t == 101:                                    # 100 warm-up steps, incl. the first update
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        action_n = act_all(trainers, obs_n)                    # every agent's actor: one launch
+        action_n = act_all(trainers, obs_n, out=env.action_views)   # every agent's actor: one launch, no copies
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
         add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n)   # one launch
         obs_n = new_obs_n
