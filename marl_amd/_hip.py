@@ -28,6 +28,7 @@ MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
 ABI_VERSION = 6
 FLAG_FORCE_TILE = 1
+ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA = 0, 1, 2
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -142,9 +143,9 @@ def _load():
     # B, ld_obs, ld_act, in_dim, s0, s1, obs, weights, u, seed, call_counter, env_id0, act, stream
     L.mpe_actor_forward_f32.restype = ci
     L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]
-    # n_jobs, jobs, B, ld_obs, ld_act, call_counter, env_id0, stream
+    # n_jobs, jobs, B, ld_obs, ld_act, call_counter, env_id0, kernel (ACTOR_*), stream
     L.mpe_actor_forward_multi_f32.restype = ci
-    L.mpe_actor_forward_multi_f32.argtypes = [ci, C.POINTER(ActorJob), i64, i64, i64, u32, u64, vp]
+    L.mpe_actor_forward_multi_f32.argtypes = [ci, C.POINTER(ActorJob), i64, i64, i64, u32, u64, ci, vp]
     L.mpe_stats_rows.restype = i64
     L.mpe_stats_rows.argtypes = [dp, i64, ci, u32]
     L.mpe_stats_reduce.restype = ci

@@ -71,12 +71,13 @@ def pack_actor(net):
                       lin[1].bias.detach(), w3.reshape(-1), b3]).contiguous()
 
 
-def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0):
-    """One launch of libmpe_hip.so:mpe_actor_forward_f32.  ``obs``: ``[B, in_dim]`` view of SoA rows (strides
-    (1, ld)), as env.step returns it.  Returns the action as the same kind of view (``[B, sum(sizes)]`` over SoA rows
-    with the same ld); env.step copies it row-wise into the env's action buffer (a per-agent list is never adopted in
-    place: only a whole [act_total, B] buffer with the world's stride is).  ``u``: optional ``[B, sum(sizes)]`` uniforms (same
-    layout) instead of the kernel's own Philox draw."""
+def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0, kernel=0):
+    """One launch of the fused actor (libmpe_hip.so: mpe_actor_forward_multi_f32 with one job).  ``obs``: ``[B, in_dim]``
+    view of SoA rows (strides (1, ld)), as env.step returns it.  Returns the action as the same kind of view
+    (``[B, sum(sizes)]`` over SoA rows with the same ld); env.step copies it row-wise into the env's action buffer (a
+    per-agent list is never adopted in place: only a whole [act_total, B] buffer with the world's stride is; see
+    ``act_all(..., out=env.action_views)`` for the copy-free form).  ``u``: optional ``[B, sum(sizes)]`` uniforms
+    (same layout) instead of the kernel's own Philox draw.  ``kernel``: _hip.ACTOR_AUTO / ACTOR_VALU / ACTOR_MFMA."""
     from . import _hip
     B, in_dim = obs.shape
     ld = obs.stride(1) if in_dim > 1 else B
@@ -87,15 +88,16 @@ def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0)
         uu[:, :B] = u.t()
         u = uu[:, :B].t()
     s0, s1 = sizes[0], (sizes[1] if len(sizes) > 1 else 0)
+    job = _hip.ActorJob(obs.data_ptr(), packed.data_ptr(), None if u is None else u.data_ptr(), act.data_ptr(), in_dim,
+                        s0, s1, seed)
     with _hip.on_device(obs.device):
-        _hip.check(_hip.lib.mpe_actor_forward_f32(B, ld, ld, in_dim, s0, s1, obs.data_ptr(), packed.data_ptr(),
-                                                  None if u is None else u.data_ptr(), seed, call_counter, env_id0,
-                                                  act.data_ptr(), _hip.stream_of(obs.device)), 'mpe_actor_forward')
+        _hip.check(_hip.lib.mpe_actor_forward_multi_f32(1, job, B, ld, ld, call_counter, env_id0, kernel,
+                                                        _hip.stream_of(obs.device)), 'mpe_actor_forward')
     return act[:, :B].t()
 
 
 @torch.no_grad()
-def act_all(trainers, obs_n, out=None):
+def act_all(trainers, obs_n, out=None, kernel=0):
     """``[tr.action(obs) for tr, obs in zip(trainers, obs_n)]`` (experiments/simple_train.py:260) with every agent's
     network + Gumbel-softmax sample in ONE launch (libmpe_hip.so: mpe_actor_forward_multi_f32).  Falls back to the
     per-agent calls when some agent's observation / model is not what the fused kernel takes.
@@ -135,7 +137,7 @@ def act_all(trainers, obs_n, out=None):
         for tr, obs, act in zip(trainers, obs_n, acts)])
     with _hip.on_device(o0.device):
         _hip.check(_hip.lib.mpe_actor_forward_multi_f32(len(trainers), jobs, B, ld, ld_act, t0._act_calls, t0.env_id0,
-                                                        _hip.stream_of(o0.device)), 'mpe_actor_forward_multi')
+                                                        kernel, _hip.stream_of(o0.device)), 'mpe_actor_forward_multi')
     return acts
 
 

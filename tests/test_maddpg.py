@@ -145,11 +145,15 @@ def test_update_follows_the_reference_arithmetic():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kernel', [1, 2], ids=['valu', 'mfma'])
 @pytest.mark.parametrize('in_dim,sizes', [(16, [5]), (34, [5, 4]), (20, [5, 7]), (3, [3]), (11, [5, 10]), (244, [5])])
-def test_fused_actor_kernel_matches_torch(in_dim, sizes):
+def test_fused_actor_kernel_matches_torch(in_dim, sizes, kernel):
     """mpe_actor_forward_f32 against the plain PyTorch fp32 forward + Gumbel-softmax with the same uniforms:
     <= 1e-5 (different summation order in the three small dot products)."""
-    from marl_amd.maddpg import actor_forward, pack_actor
+    import functools
+    from marl_amd import maddpg
+    from marl_amd.maddpg import pack_actor
+    actor_forward = functools.partial(maddpg.actor_forward, kernel=kernel)   # vector kernel / matrix-core kernel
     torch.manual_seed(in_dim)
     B, ld = 5000 + 13, 5376
     net = mlp_model(in_dim, sum(sizes)).cuda()
@@ -203,6 +207,7 @@ def test_fused_actor_extreme_uniforms_and_sharded_noise():
     a large batch; (c) the draw is keyed by the GLOBAL env id: shards [0, B) and [B, 2B) with env_id0 = 0 / B
     reproduce the single 2B-env call bit for bit (env-sharded multi-GPU runs explore identically whatever the
     world size)."""
+    from marl_amd import maddpg
     from marl_amd.maddpg import actor_forward, pack_actor
     torch.manual_seed(5)
     sizes, in_dim = [5, 7], 20
@@ -233,6 +238,10 @@ def test_fused_actor_extreme_uniforms_and_sharded_noise():
     assert torch.equal(whole[:B], first) and torch.equal(whole[B:], second)
     wrong = actor_forward(packed, second_rows[:, :B].t(), sizes, seed=3, call_counter=9, env_id0=1000)
     assert not torch.equal(whole[B:], wrong)
+    # the vector kernel and the matrix-core kernel draw the same noise: equal up to the summation order of the dot products
+    a1 = maddpg.actor_forward(packed, rows2[:, :B2].t(), sizes, seed=3, call_counter=9, env_id0=1000, kernel=1)
+    a2 = maddpg.actor_forward(packed, rows2[:, :B2].t(), sizes, seed=3, call_counter=9, env_id0=1000, kernel=2)
+    assert float((a1 - a2).abs().max()) <= 1e-5 and torch.equal(whole, a1)      # AUTO = the vector kernel
 
 
 @pytest.mark.gpu

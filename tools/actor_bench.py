@@ -17,19 +17,20 @@ def main():
         net = mlp_model(in_dim, sum(sizes)).cuda()
         packed = pack_actor(net)
         obs = torch.randn(in_dim, ld, device='cuda')[:, :B].t()
-        for c in range(3):
-            actor_forward(packed, obs, sizes, seed=1, call_counter=c)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for c in range(20):
-            actor_forward(packed, obs, sizes, seed=1, call_counter=c)
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 20 * 1e-3
-        flop = 2.0 * B * (in_dim * 64 + 64 * 64 + 64 * (8 if sum(sizes) <= 8 else 16))   # columns the kernel evaluates
-        print('actor %3d -> 64 -> 64 -> %-7s %d envs: %7.1f us  %5.1f TFLOP/s f32  %5.0f GB/s' %
-              (in_dim, sizes, B, t * 1e6, flop / t / 1e12, 4.0 * B * (in_dim + sum(sizes)) / t / 1e9))
+        for kernel, name in ((1, 'vector FMA'), (2, 'f32 MFMA')):
+            for c in range(3):
+                actor_forward(packed, obs, sizes, seed=1, call_counter=c, kernel=kernel)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for c in range(20):
+                actor_forward(packed, obs, sizes, seed=1, call_counter=c, kernel=kernel)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / 20 * 1e-3
+            flop = 2.0 * B * (in_dim * 64 + 64 * 64 + 64 * sum(sizes))   # useful flop (the kernels evaluate 8 / 16 / 32 columns)
+            print('actor %3d -> 64 -> 64 -> %-7s %d envs, %-10s: %7.1f us  %5.1f useful TFLOP/s f32  %5.0f GB/s' %
+                  (in_dim, sizes, B, name, t * 1e6, flop / t / 1e12, 4.0 * B * (in_dim + sum(sizes)) / t / 1e9))
 
 
 if __name__ == '__main__':
