@@ -278,8 +278,10 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
                 e1.record()
                 events.append((e0, e1, length))
 
+    use_dist = dist.is_initialized()
+
     def fence():
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -293,7 +295,7 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     run(segs_timed, events, count=True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world_size > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -324,8 +326,8 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
                    'launch': 'hip graph per run of steps between episode boundaries' if graphs else 'one host call per step',
                    'graph_replays': counts['graph_replays'], 'eager_steps': counts['eager_steps'],
                    'benchmark_info': has_info,
-                   'stats_allreduce': 'per episode' if world_size > 1 else 'per episode (single rank: local reduce)',
-                   'parallelism': 'env-sharded dp%d' % world_size, 'backend': backend if world_size > 1 else None},
+                   'stats_allreduce': 'per episode' if use_dist else 'per episode (single rank: local reduce)',
+                   'parallelism': 'env-sharded dp%d' % world_size, 'backend': backend if use_dist else None},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,
                      'traffic': measured_traffic(name) if B == envs_per_gpu else None,
@@ -378,7 +380,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     import torch.distributed as dist
-    if world_size > 1:
+    # under torch.distributed.run the process group is initialised even for ONE rank, so that `--gpus 1` launched by
+    # the driver's own command line runs the same RCCL calls (barrier, all-reduce of the statistics and of the time)
+    # as the N > 1 runs
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    if world_size > 1 or launched:
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
@@ -397,7 +403,7 @@ def main():
                 out['other_configs'][name] = {k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype',
                                                                  'config', 'roofline')}
         print(json.dumps(out))
-    if world_size > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -187,14 +187,14 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
     const int64_t ge = active ? env : (p.B - 1);  // inactive lanes shadow the last env, never store
 
     // ---- phase 0 ------------------------------------------------------------------------------
-    for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = p.pos[(int64_t)r * ld + ge];
+    for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = ld_state(p.pos + (int64_t)r * ld + ge);
     // Inputs of one agent of one env: old velocity, the four action entries that matter, u_noise normals.  Fetched one
     // agent ahead of the pair loop (and the first one here, beside the position loads), so that the HBM latency of
     // these read-once rows -- several microseconds while the chip streams observations -- hides behind compute.
     struct AgentIn { T vx, vy, a1, a2, a3, a4, nx, ny; };
     auto fetch = [&](int a, AgentIn &in) {
-      in.vx = p.vel[(int64_t)(2 * a) * ld + ge];
-      in.vy = p.vel[(int64_t)(2 * a + 1) * ld + ge];
+      in.vx = ld_state(p.vel + (int64_t)(2 * a) * ld + ge);
+      in.vy = ld_state(p.vel + (int64_t)(2 * a + 1) * ld + ge);
       in.a1 = in.a2 = in.a3 = in.a4 = in.nx = in.ny = T(0);
       if (bit(d.movable, a)) {
         const T *ar = p.act + (int64_t)(HIER ? d.act_row0[a] : 5 * a) * ld + ge;  // environment.py:188-190
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
     AgentIn nxt;
     if (DO_STEP && chunk < A) fetch(chunk, nxt);
     if (!DO_STEP) {
-      for (int r = chunk; r < 2 * A; r += NCH) sVel[r * TILE + lane] = p.vel[(int64_t)r * ld + ge];
+      for (int r = chunk; r < 2 * A; r += NCH) sVel[r * TILE + lane] = ld_state(p.vel + (int64_t)r * ld + ge);
       if (has_lf)
         for (int r = chunk; r < 2 * A; r += NCH) sLf[r * TILE + lane] = p.lforce[(int64_t)r * ld + ge];
     }
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           }
           integrate_vel<T>(vx, vy, Fx, Fy, d.mass[a], d.damp1, d.dt, d.max_speed[a]);
           if (active) {
-            p.vel[(int64_t)(2 * a) * ld + env] = vx;
-            p.vel[(int64_t)(2 * a + 1) * ld + env] = vy;
+            st_state(p.vel + (int64_t)(2 * a) * ld + env, vx);
+            st_state(p.vel + (int64_t)(2 * a + 1) * ld + env, vy);
           }
         }
         sVel[(2 * a) * TILE + lane] = vx;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const int r = 2 * a + c;
             const T np_ = sPos[r * TILE + lane] + sVel[r * TILE + lane] * d.dt;
             sPos[r * TILE + lane] = np_;
-            if (active) p.pos[(int64_t)r * ld + env] = np_;
+            if (active) st_state(p.pos + (int64_t)r * ld + env, np_);
           }
         }
         if (p.comm != nullptr && active) {  // core.py:226-230 (c_noise is rejected on the host)

@@ -18,7 +18,7 @@ def shard_range(total_envs, rank, world_size):
 
 def all_reduce_stats(vec, group=None):
     """Sum the statistics vector over ranks in place (no-op without an initialised process group)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         if vec.is_cuda and dist.get_backend(group) == 'gloo':
             # CPU rehearsal backend: stage through the host (RCCL reduces the device tensor directly)
             host = vec.cpu()

@@ -65,3 +65,20 @@ def test_graph_replay_equals_eager_stepping():
     e = _single(30_011, '--no-graph')
     assert g['config']['graph_replays'] == 2 and e['config']['eager_steps'] == 50
     assert g['episode_stats_vector'] == e['episode_stats_vector']
+
+
+def test_single_rank_under_torchrun_runs_the_rccl_path():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (backend nccl = RCCL): the barrier and the all-reduces
+    of the statistics vector and of the elapsed time execute on the device communicator, with the result of the plain run.
+    (More than one rank needs more than one GPU with RCCL; the two-rank test above uses gloo.)"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--envs', '30011'] + COMMON
+    one = _json(subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env))
+    assert one['n_gpus'] == 1 and one['config']['backend'] == 'nccl' and one['config']['stats_allreduce'] == 'per episode'
+    plain = _single(30_011)
+    assert plain['config']['backend'] is None
+    assert one['episode_stats_vector'] == plain['episode_stats_vector']
