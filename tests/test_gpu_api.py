@@ -506,3 +506,50 @@ def test_library_calls_run_on_the_worlds_device():
     env.reset()
     env.step(torch.rand(32, 4, 5, device='cuda'))
     assert torch.cuda.current_device() == cur
+
+
+@pytest.mark.parametrize('scenario,noise', [('simple_tag', True), ('S1L2F2_10Targets_wide', False), ('simple_world_comm', False)])
+def test_captured_steps_replay_equals_eager_stepping(scenario, noise):
+    """marl_amd.graph.CapturedSteps: K env.step launches recorded in a HIP graph and replayed with one host call leave
+    the world, the outputs and the Python-side bookkeeping exactly as K eager steps do (ragged action rows, recorded
+    u_noise draws, statistics rows included); a second replay continues from there."""
+    from marl_amd import make_env
+    from marl_amd.graph import CapturedSteps
+    B, K = 3001, 7
+
+    def build():
+        env = make_env(scenario, benchmark=True, num_envs=B, dtype=torch.float32, seed=11)
+        w = env.world
+        if noise:
+            for a in w.agents:
+                a.u_noise = 0.3
+            w.invalidate_descriptor()
+            w.noise = torch.randn(len(w.agents), 2, B, generator=torch.Generator(device='cuda').manual_seed(3), device='cuda')
+        w.enable_stats()
+        g = torch.Generator(device='cuda').manual_seed(5)
+        acts = []
+        for _ in range(K):
+            a = w.new_action_buffer()
+            a.copy_(torch.rand(a.shape, generator=g, device='cuda'))
+            acts.append(a)
+        env.reset()
+        return env, acts
+    e1, a1 = build()
+    e2, a2 = build()
+    cap = CapturedSteps(e2, a2)
+    assert torch.equal(e1.world.pos, e2.world.pos) and torch.equal(e1.world.stats, e2.world.stats)   # capture ran nothing
+    for rnd in range(2):
+        for a in a1:
+            out1 = e1.step(a)
+        out2 = cap.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(out1[0] + out1[1], out2[0] + out2[1]):                      # observations and rewards
+            assert torch.equal(x, y)
+        w1, w2 = e1.world, e2.world
+        assert torch.equal(w1.pos, w2.pos) and torch.equal(w1.vel, w2.vel) and torch.equal(w1.stats, w2.stats)
+        assert torch.equal(w1.info, w2.info) and (w1.lforce is None or torch.equal(w1.lforce, w2.lforce))
+        assert w2.obs_views[0].data_ptr() == out2[0][0].data_ptr()           # world.obs points at the replay's last buffer
+        # scenario callbacks after a replay serve the replay's last outputs without a new launch
+        assert torch.equal(e2.reward_callback(w2.agents[0], w2), out2[1][0])
+    with pytest.raises(ValueError):                                              # not the world's row stride: refused
+        CapturedSteps(e2, [torch.zeros(tuple(a2[0].shape), device='cuda')])
