@@ -84,9 +84,13 @@ class MultiAgentEnv(object):
     # -- environment.py:157-208: the decode itself runs inside the kernel ------------------------------
     def _set_actions(self, action_n):
         act = self.world.act
-        if torch.is_tensor(action_n) and action_n.dim() == act.dim() \
-                and tuple(action_n.shape) == tuple(act.shape) and action_n.dtype == act.dtype \
-                and action_n.device == act.device and (self.num_envs, self.n) != (5, 5):
+        soa = (torch.is_tensor(action_n) and action_n.dim() == act.dim() and tuple(action_n.shape) == tuple(act.shape)
+               and action_n.dtype == act.dtype and action_n.device == act.device)
+        if soa and act.dim() == 3 and tuple(action_n.shape) == (self.num_envs, self.n, 5):
+            # [n, 5, B] and [B, n, 5] coincide (B = n = 5): only a tensor with the world's own row stride
+            # (world.new_action_buffer()) is read as the SoA layout, anything else as the reference-like [B, n, 5]
+            soa = action_n.stride() == self._own_act.stride()
+        if soa:
             # SoA path: an [n, 5, B] ([act_total, B]) tensor is the kernel's own layout.  With the
             # world's row stride (world.new_action_buffer()) it is adopted in place, no copy;
             # env.action_views keep pointing at the env's original buffer.  Any other strides: one

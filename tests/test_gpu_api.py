@@ -553,3 +553,23 @@ def test_captured_steps_replay_equals_eager_stepping(scenario, noise):
         assert torch.equal(e2.reward_callback(w2.agents[0], w2), out2[1][0])
     with pytest.raises(ValueError):                                              # not the world's row stride: refused
         CapturedSteps(e2, [torch.zeros(tuple(a2[0].shape), device='cuda')])
+
+
+def test_ambiguous_action_tensor_shape_is_decided_by_the_row_stride():
+    """With 5 agents and 5 envs an [n, 5, B] SoA tensor and a reference-like [B, n, 5] tensor have the same shape:
+    only a buffer with the world's own row stride (world.new_action_buffer()) is read as SoA."""
+    from marl_amd import make_env
+    env = make_env('simple_tag', num_envs=5, dtype=torch.float64, seed=2, num_adversaries=4, num_good_agents=1)
+    assert env.n == 5 and env.num_envs == 5
+    act = torch.softmax(torch.randn(5, 5, 5, device='cuda', dtype=torch.float64), -1)        # [B, n, 5]
+    env.reset()
+    state = (env.world.pos.clone(), env.world.vel.clone())
+    o1 = [o.clone() for o in env.step(act)[0]]
+    env.world.pos.copy_(state[0]); env.world.vel.copy_(state[1]); env.world.mark_dirty()
+    o2 = [o.clone() for o in env.step([act[:, i] for i in range(5)])[0]]                    # per-agent list: unambiguous
+    env.world.pos.copy_(state[0]); env.world.vel.copy_(state[1]); env.world.mark_dirty()
+    soa = env.world.new_action_buffer()
+    soa.copy_(act.permute(1, 2, 0))                                                          # [n, 5, B], world stride
+    o3 = [o.clone() for o in env.step(soa)[0]]
+    for a, b, c in zip(o1, o2, o3):
+        assert torch.equal(a, b) and torch.equal(a, c)
