@@ -338,22 +338,26 @@ __device__ __forceinline__ bool kind_is_comm(int kind) {
   return kind == MPE_SPEAKER_LISTENER || kind == MPE_SIMPLE_REFERENCE;
 }
 
-// is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): sqrt(dx^2 + dy^2) < dmin, strict.
+// is_collision (simple_tag.py:69-73 / simple_spread.py:65-69): sqrt(d2) < dmin, strict, for d2 = dx^2 + dy^2.
 template <typename T>
-__device__ __forceinline__ bool touching(T dx, T dy, T dmin) {
-  return t_sqrt<T>(dx * dx + dy * dy) < dmin;
+__device__ __forceinline__ bool touching_d2(T d2, T dmin) {
+  return t_sqrt<T>(d2) < dmin;
 }
 // f64: the same boolean without the ~25-instruction correctly rounded square root.  sqrt is monotonic, so away from
 // the threshold the squares decide: d2 < dmin^2 (1 - 2^-50) implies sqrt(d2) < dmin (1 - 2^-51.2), which rounds to a
 // double below dmin; d2 > dmin^2 (1 + 2^-50) likewise rounds to one >= dmin.  Inside that band (a few ulps; about one
 // contact test in 10^15) the reference's expression itself is evaluated.  NaN -> false both ways.
 template <>
-__device__ __forceinline__ bool touching<double>(double dx, double dy, double dmin) {
-  const double d2 = dx * dx + dy * dy, m2 = dmin * dmin;
+__device__ __forceinline__ bool touching_d2<double>(double d2, double dmin) {
+  const double m2 = dmin * dmin;
   const double lo = m2 * (1.0 - 0x1p-50), hi = m2 * (1.0 + 0x1p-50);
   bool r = d2 < lo;
   if (d2 >= lo && d2 <= hi) r = sqrt(d2) < dmin;
   return r;
+}
+template <typename T>
+__device__ __forceinline__ bool touching(T dx, T dy, T dmin) {
+  return touching_d2<T>(dx * dx + dy * dy, dmin);
 }
 
 // bound() of simple_tag.agent_reward (simple_tag.py:103-108), x = |pos|.

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         tdx[l] = px[A + l] - px[i];
         tdy[l] = py[A + l] - py[i];
         td2[l] = tdx[l] * tdx[l] + tdy[l] * tdy[l];
-        n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;
+        n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;  // (the sqrt-free f64 test costs registers here: +2 %)
       }
       hits[i] = n;
       if (!want_obs) continue;
@@ -227,7 +227,9 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         wobs.st_stream(r++, lo, lfx[i]);
         wobs.st_stream(r++, lo, lfy[i]);
       }
-      // visible targets, nearest first, ties by index (stable sort, :242-245), then zeros
+      // visible targets, nearest first, ties by index (stable sort, :242-245), then zeros.  (A single pass that keeps
+      // the three best was tried in round 2: same time in f32, and in f64 its nine extra live doubles push the 10-target
+      // kernel from 225 to 274 VGPRs = one wavefront per SIMD, 673 -> 1 035 us.)
       T prev_d = T(0);
       int prev_l = -1;
 #pragma unroll
