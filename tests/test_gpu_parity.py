@@ -279,6 +279,59 @@ def test_config5_scaled_tag_f64_and_f32_vs_oracle():
     assert (rew[:48] > 0).any() and (rew[48:] <= -10).any()
 
 
+def test_config5_scaled_tag_262144_f32_properties():
+    """BASELINE config 5 at its full size (262,144 envs of 48 + 16 agents / 32 landmarks, f32, the LDS-tile kernel with
+    the 16-byte observation stores): size-independent properties on the whole batch -- run-to-run determinism, every
+    observation row of four agents rebuilt exactly from the state (simple_tag.py:131-147), reward / benchmark
+    consistency (:57-66, 115-129) -- and a 256-env sample of the last step against the oracle."""
+    spec = O.simple_tag_spec(48, 16, 32)
+    A, L, E, B, T = 64, 32, 96, 1 << 18, 3
+    g = torch.Generator(device='cuda').manual_seed(9)
+    pos0 = torch.rand(E, 2, B, generator=g, device='cuda') * 1.6 - 0.8
+    vel0 = torch.rand(A, 2, B, generator=g, device='cuda') * 0.4 - 0.2
+    acts = [torch.softmax(torch.randn(A, 5, B, generator=g, device='cuda'), dim=1) for _ in range(T)]
+    sim = HipSim(spec, B, torch.float32)
+    first = None
+    for rep in range(2):
+        sim.pos.copy_(pos0)
+        sim.vel.copy_(vel0)
+        for t in range(T):
+            if t == T - 1:
+                before = (sim.pos.clone(), sim.vel.clone())
+            sim.env_step(acts[t])
+        if first is None:
+            first = tuple(x.clone() for x in (sim.pos, sim.vel, sim.rew, sim.info))
+            obs_sum = sim.obs.sum(dtype=torch.float64)
+            obs_first = sim.obs[:452].clone()                            # agents 0 and 1 (15 GB: not cloned whole)
+    for x, y in zip(first, (sim.pos, sim.vel, sim.rew, sim.info)):
+        assert torch.equal(x, y)
+    assert torch.equal(obs_first, sim.obs[:452]) and obs_sum == sim.obs.sum(dtype=torch.float64)
+    assert torch.isfinite(sim.rew).all()
+    # observation rows vs state, exact (f32 subtractions of the same operands)
+    row0 = lambda i: 226 * i if i < 48 else 226 * 48 + 224 * (i - 48)
+    for i in (0, 47, 48, 63):
+        o = sim.obs[row0(i):row0(i) + (226 if i < 48 else 224)]
+        others = [j for j in range(A) if j != i]
+        want = torch.cat([sim.vel[i], sim.pos[i], (sim.pos[A:] - sim.pos[i]).reshape(2 * L, B),
+                          (sim.pos[others] - sim.pos[i]).reshape(2 * (A - 1), B),
+                          sim.vel[[j for j in range(48, A) if j != i]].reshape(-1, B)])
+        assert want.shape == o.shape and torch.equal(o, want), i
+    # every adversary gets 10 x (all good-adversary contacts); its benchmark count is its own contacts; good agents report 0
+    total = sim.info[:48, 0].sum(0)
+    assert (total > 0).any() and (sim.info[48:] == 0).all()
+    for a in (0, 17, 47):
+        assert torch.equal(sim.rew[a], 10 * total)
+    assert (sim.rew[48:] <= 0).all()
+    # the last step of a 256-env sample, from the same pre-step state, against the oracle (f32 vs f64: 1e-4)
+    idx = torch.arange(0, B, B // 256, device='cuda')[:256]
+    p, v = (x[:, :, idx].double().cpu().numpy() for x in before)
+    p, v, obs, rew, info = O.BatchedOracle(spec).env_step(p, v, acts[T - 1][:, :, idx].double().cpu().numpy())
+    np.testing.assert_allclose(sim.pos[:, :, idx].double().cpu().numpy(), p, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sim.vel[:, :, idx].double().cpu().numpy(), v, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(sim.obs[:, idx].double().cpu().numpy(), np.concatenate(obs, 0), rtol=1e-4, atol=2e-4)
+    assert np.mean(np.abs(sim.rew[:, idx].double().cpu().numpy() - rew) <= 1e-3) > 0.98
+
+
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
 def test_reset_matches_philox_oracle(dtype, force_tile):
     """mpe_reset_* draws exactly the oracle's Philox stream; masked envs untouched; the result does
