@@ -238,11 +238,15 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     stats_total.add_(stats.read())      # also loads torch's f64 add kernel (a ~20 ms one-time cost)
     stats_total.zero_()
     stats.reset()
-    graphs = {}
+    graphs, graph_error = {}, None
     if use_graph:
-        for _, pos, length in segs_warm + segs_timed:
-            if (pos, length) not in graphs and length > 1:
-                graphs[(pos, length)] = CapturedSteps(env, [pool[(pos + k) % POOL] for k in range(length)])
+        try:
+            for _, pos, length in segs_warm + segs_timed:
+                if (pos, length) not in graphs and length > 1:
+                    graphs[(pos, length)] = CapturedSteps(env, [pool[(pos + k) % POOL] for k in range(length)])
+        except RuntimeError as e:          # a capture that fails must not cost the run: step eagerly instead
+            graphs, graph_error = {}, str(e).splitlines()[0][:200]
+            torch.cuda.synchronize()
         stats.reset()
     torch.cuda.synchronize()
 
@@ -325,6 +329,7 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
                    'timed_region_starts_at_episode_step': pos_timed,
                    'launch': 'hip graph per run of steps between episode boundaries' if graphs else 'one host call per step',
                    'graph_replays': counts['graph_replays'], 'eager_steps': counts['eager_steps'],
+                   'graph_capture_error': graph_error,
                    'benchmark_info': has_info,
                    'stats_allreduce': 'per episode' if use_dist else 'per episode (single rank: local reduce)',
                    'parallelism': 'env-sharded dp%d' % world_size, 'backend': backend if use_dist else None},

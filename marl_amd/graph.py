@@ -31,8 +31,11 @@ class CapturedSteps(object):
         self._restore(state)
         self._slot0 = w._obs_slot
         self.graph = torch.cuda.CUDAGraph()
+        # thread_local: another thread's HIP calls (the RCCL watchdog of torch.distributed polls events) must not
+        # invalidate the capture; everything enqueued so far is drained first
+        torch.cuda.synchronize(w.device)
         with _hip.on_device(w.device):
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 for a in self.actions:
                     self.last = env.step(a)
         self._slot_after = w._obs_slot
