@@ -105,6 +105,19 @@ int main() {
   REC_RUN(false, 512, true, 56 * 1024)
   REC_RUN(false, 256, true, 40 * 1024)
   REC_RUN(false, 1024, true, 80 * 1024)
+  // row stride: B + pad floats (the world's default is 1 KiB past a multiple of 4 KiB = pad 256 floats)
+  for (long padb : {0L, 256L, 1024L, 4096L + 1024, 16384L + 1024, 65536L + 1024, 131072L + 1024, 262144L + 1024, 524288L + 1024}) {
+    const long ldp = B + padb / 4;
+    if ((size_t)ROWS * ldp > (size_t)(ROWS + 256) * LD + 0) {
+      // buffer holds (ROWS + 256) * LD floats: fewer rows for the big pads
+    }
+    const long rows = ((ROWS + 256) * LD) / ldp < ROWS ? ((ROWS + 256) * LD) / ldp : ROWS;
+    auto k = tile_rows<false, 256, 512>; SETLDS(k, 160 * 1024);
+    float ms = time_it([&] { hipLaunchKernelGGL(k, dim3(B * 4 / 256), dim3(512), 80 * 1024, 0, out, ldp, rows); });
+    printf("row segments of 256 B, 512 thr, LDS 80 KiB, row stride 1 MiB + %7ld B, %5ld rows: %8.3f ms  %7.1f GB/s\n", padb, rows, ms,
+           (double)rows * B * 4 / ms / 1e6);
+    fflush(stdout);
+  }
   TILE_RUN(false, 256, 256, 0)
   TILE_RUN(true, 256, 256, 0)
   TILE_RUN(false, 256, 512, 0)
