@@ -187,8 +187,8 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     has_info = scenario not in ('simple', 'simple_push', 'simple_speaker_listener', 'simple_reference')
     env = make_env(scenario, benchmark=has_info, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
     env.world.env_id0 = env_id0
-    if os.environ.get('MPE_FORCE_TILE'):      # tuning aid: run the stock worlds on the generic LDS-tile kernel
-        env.world.set_flags(_hip.FLAG_FORCE_TILE)
+    if os.environ.get('MPE_FLAGS'):           # tuning aid: kernel selection flags (include/mpe_hip.h, MPE_FLAG_*)
+        env.world.set_flags(int(os.environ['MPE_FLAGS']))
     n = env.n
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
 

@@ -97,6 +97,12 @@ extern "C" {
 /* mpe_buffers.flags bits (per call; 0 = default behaviour) */
 #define MPE_FLAG_FORCE_TILE 1u   /* run the generic LDS-tile kernel even for a world that has a register-resident
                                     kernel (tests check both kernels against the same golden vectors; tuning)  */
+#define MPE_FLAG_WIDE 2u         /* simple_tag / simple_spread: always one env per lane, never the small-batch form  */
+#define MPE_FLAG_SPLIT 4u        /* simple_tag / simple_spread: one agent per wavefront (the small-batch form,
+                                    default for B <= MPE_SPLIT_MAX_ENVS) at any batch size.  Both forms produce the
+                                    same bits; the statistics rows group 64 envs instead of 256                      */
+#define MPE_FLAG_ALL 7u
+#define MPE_SPLIT_MAX_ENVS 32768
 
 /*
  * World + scenario constants: what Scenario.make_world() sets up (simple_tag.py:7-36,

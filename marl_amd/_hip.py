@@ -28,6 +28,9 @@ MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
 ABI_VERSION = 6
 FLAG_FORCE_TILE = 1
+FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
+FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
+SPLIT_MAX_ENVS = 32768
 ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA = 0, 1, 2
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)

@@ -420,7 +420,7 @@ static SmallId small_variant(const mpe_scenario_desc *h) {
   return id;
 }
 
-// Workgroup size of the register kernel for this launch, or 0 = use the tile kernel.
+// Envs per workgroup of the register kernel for this launch (= its statistics rows per env), or 0 = use the tile kernel.
 // simple_push (10 agents) needs ~164 VGPRs in f32 (no 1024-lane workgroups) and > 256 in f64
 // (register kernel would spill: the tile kernel takes it).
 static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, uint32_t flags, SmallId *out) {
@@ -430,6 +430,7 @@ static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype
   if (out) *out = sv;
   if (sv == SMALL_NONE) return 0;
   if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
+  if (small_id_splits(sv, B, flags)) return kSplitEnvs;
   return kSmallThreads;
 }
 
@@ -442,7 +443,7 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, uint32_t flag
     bool noise = false;
     if (DO_STEP && p.noise != nullptr)
       for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
-    return launch_stock_id<T, DO_STEP, DO_OBS>(sv, p, noise, s);
+    return launch_stock_id<T, DO_STEP, DO_OBS>(sv, p, noise, small_id_splits(sv, p.B, flags), s);
   }
   return launch_tile_world<T, DO_STEP, DO_OBS>(h, p, s);
 }
@@ -452,7 +453,7 @@ extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dty
   if (rc) return rc;
   if (B < 1) return MPE_ERR_BATCH;
   if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
-  if (flags & ~(uint32_t)MPE_FLAG_FORCE_TILE) return MPE_ERR_ARG;
+  if (flags & ~(uint32_t)MPE_FLAG_ALL) return MPE_ERR_ARG;
   const int threads = small_launch_threads(h, B, dtype_bytes, flags, nullptr);
   if (threads != 0) return (B + threads - 1) / threads;
   return tile_grid(B, dtype_bytes == 4 ? tile_envs<float>() : tile_envs<double>());
@@ -476,7 +477,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   int rc = check_common<T>(h, B, ld);
   if (rc) return rc;
   if (!b || !b->pos || !b->vel) return MPE_ERR_NULL;
-  if (b->flags & ~(uint32_t)MPE_FLAG_FORCE_TILE) return MPE_ERR_ARG;
+  if (b->flags & ~(uint32_t)MPE_FLAG_ALL) return MPE_ERR_ARG;
   if (do_step && !b->act) return MPE_ERR_NULL;
   const bool lf = has_lforce(h);
   if (lf && !b->lforce) return MPE_ERR_NULL;

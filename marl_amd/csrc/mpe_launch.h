@@ -29,6 +29,16 @@ enum SmallId {
 };
 
 constexpr int kSmallThreads = 256;  // workgroup of the one-env-per-lane register kernels
+// (simple_tag 1 Mi envs f32, r2: 128 lanes 86.6 us, 256 lanes 78.9, 512 lanes 85.8)
+// Small batches of simple_tag / simple_spread (B <= MPE_SPLIT_MAX_ENVS, include/mpe_hip.h) run one AGENT per wavefront
+// instead (mpe_split_kernel.h): a workgroup is 64 envs x A wavefronts.  Well below one wavefront per SIMD the
+// one-env-per-lane kernel is bound by the latency of its own instruction stream, and the split form shortens it by ~A.
+constexpr int kSplitEnvs = 64;
+inline bool small_id_splits(SmallId sv, int64_t B, uint32_t flags) {
+  if (sv != SMALL_TAG_3_1_2 && sv != SMALL_SPREAD_3_3) return false;
+  if (flags & MPE_FLAG_SPLIT) return true;
+  return !(flags & MPE_FLAG_WIDE) && B <= (int64_t)MPE_SPLIT_MAX_ENVS;
+}
 constexpr int kHierDimC = 7;        // stock shape of the L1F* / S1L* Targets files
 constexpr int kHierTargets = 3;
 
@@ -52,7 +62,7 @@ int launch_tile_world(const mpe_scenario_desc *h, const KParams<T> &p, hipStream
 // Run the register kernel `sv` (one env per lane, stock shapes): the stock scenarios' kernels are defined in
 // mpe_small_f32.hip / mpe_small_f64.hip, the command-hierarchy ones in mpe_hier_f32.hip / mpe_hier_f64.hip.
 template <typename T, bool DO_STEP, bool DO_OBS>
-int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s);
+int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, bool split, hipStream_t s);
 template <typename T, bool DO_STEP, bool DO_OBS>
 int launch_hier_id(SmallId sv, const KParams<T> &p, hipStream_t s);
 inline bool small_id_is_hier(SmallId sv) { return (sv >= HIER_FIRST && sv <= HIER_LAST) || sv == MOVING_6_4_3 || sv == MOVING_8_4_7; }

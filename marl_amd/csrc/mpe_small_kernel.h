@@ -38,6 +38,11 @@ namespace mpe {
 constexpr int small_wave_cap(int kind, int elem_bytes) {
   return kind == MPE_SIMPLE ? 8 : (kind == MPE_SIMPLE_TAG && elem_bytes == 8 ? 5 : 3);
 }
+#ifdef MPE_ABL_NO_STATS  // ablation: what the per-workgroup statistics epilogue costs
+#define MPE_WANT_STATS(x) false
+#else
+#define MPE_WANT_STATS(x) (x)
+#endif
 #ifndef MPE_SMALL_ATTR
 #define MPE_SMALL_ATTR __attribute__((amdgpu_waves_per_eu(1, small_wave_cap(KIND, (int)sizeof(T)))))
 #endif
@@ -67,6 +72,14 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
   for (int a = 0; a < A; ++a) {
     vx[a] = wvel.ld_state(2 * a, lo);
     vy[a] = wvel.ld_state(2 * a + 1, lo);
+  }
+  // simple_tag / simple_spread: this block's statistics row is fetched with the state, so that the read-modify-write
+  // at the very end of the kernel does not hold the workgroup's slot for one more memory round trip (simple_tag f32
+  // 81.7 -> 79.8 us, f64 195.8 -> 192.9).  The same in the other register kernels is neutral (hierarchy, world_comm) or
+  // costs 1-3 % (simple_adversary, speaker_listener, simple_crypto: A/B on one box, r2), so they keep the plain `+=`.
+  double stats_prev = 0.0;
+  if constexpr (DO_OBS && !F1) {
+    if (p.stats != nullptr && threadIdx.x < 2 * A + 2) stats_prev = p.stats[(int64_t)blockIdx.x * (2 * A + 2) + threadIdx.x];
   }
 
   if (DO_STEP) {
@@ -232,6 +245,11 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
   }
 
   if constexpr (DO_OBS && !F1) {
+#ifndef MPE_NO_SYNC_OBS
+    // the four wavefronts of a workgroup start their store streams together: each row then gets its 1 KiB piece from
+    // one workgroup at about the same time (simple_tag f32 79.6 -> 78.8 us, r2 A/B; tail lanes take no early exit)
+    __syncthreads();
+#endif
     // ---- observations (simple_tag.py:131-147 / simple_spread.py:83-99) ---------------------------
     if (p.obs != nullptr) {
 #pragma unroll
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
       }
     }
     // ---- reward / info ------------------------------------------------------------------------
-    const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;
+    const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = MPE_WANT_STATS(p.stats != nullptr);
     if (want_rew || want_info || want_stats) {
       const Win<T> wrew(p.rew + blk0, ld), winfo(p.info + blk0, ld);
       T rew[A];
@@ -383,7 +401,7 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
           double s = 0.0;
 #pragma unroll
           for (int w = 0; w < NW; ++w) s += sred[w][threadIdx.x];
-          p.stats[(int64_t)blockIdx.x * W + threadIdx.x] += s;
+          p.stats[(int64_t)blockIdx.x * W + threadIdx.x] = stats_prev + s;
         }
       }
     }

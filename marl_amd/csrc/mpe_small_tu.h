@@ -7,6 +7,7 @@
 #include "mpe_comm_kernel.h"
 #include "mpe_wcomm_kernel.h"
 #include "mpe_small_kernel.h"
+#include "mpe_split_kernel.h"
 
 namespace mpe {
 
@@ -21,6 +22,17 @@ static int launch_small(const KParams<T> &p, bool noise, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// small batches: one agent per wavefront, 64 envs per workgroup (mpe_split_kernel.h)
+template <typename T, int KIND, int A, int L, int NADV, bool DO_STEP, bool DO_OBS>
+static int launch_split(const KParams<T> &p, bool noise, hipStream_t s) {
+  const dim3 grid((unsigned)((p.B + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitEnvs * A);
+  if (noise)
+    hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, int KIND, int C, bool DO_STEP, bool DO_OBS>
 static int launch_comm(const KParams<T> &p, hipStream_t s) {
   const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
@@ -29,7 +41,7 @@ static int launch_comm(const KParams<T> &p, hipStream_t s) {
 }
 
 template <typename T, bool DO_STEP, bool DO_OBS>
-int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) {
+int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, bool split, hipStream_t s) {
   const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
   switch (sv) {
     case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
@@ -40,8 +52,12 @@ int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) 
     case COMM_CRYPTO:
       hipLaunchKernelGGL((crypto_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
       return (int)hipGetLastError();
-    case SMALL_TAG_3_1_2: return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, DO_STEP, DO_OBS>(p, noise, s);
-    case SMALL_SPREAD_3_3: return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, DO_STEP, DO_OBS>(p, noise, s);
+    case SMALL_TAG_3_1_2:
+      if (split) return launch_split<T, MPE_SIMPLE_TAG, 4, 2, 3, DO_STEP, DO_OBS>(p, noise, s);
+      return launch_small<T, MPE_SIMPLE_TAG, 4, 2, 3, DO_STEP, DO_OBS>(p, noise, s);
+    case SMALL_SPREAD_3_3:
+      if (split) return launch_split<T, MPE_SIMPLE_SPREAD, 3, 3, 0, DO_STEP, DO_OBS>(p, noise, s);
+      return launch_small<T, MPE_SIMPLE_SPREAD, 3, 3, 0, DO_STEP, DO_OBS>(p, noise, s);
     case SMALL_SIMPLE_1_1: return launch_small<T, MPE_SIMPLE, 1, 1, 0, DO_STEP, DO_OBS>(p, noise, s);
     case SMALL_ADVERSARY_3_2: return launch_small<T, MPE_SIMPLE_ADVERSARY, 3, 2, 1, DO_STEP, DO_OBS>(p, noise, s);
     case SMALL_PUSH_10_1:  // f64 needs > 256 VGPRs: the host routes it to the tile kernel (small_launch_threads)
@@ -51,8 +67,8 @@ int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, hipStream_t s) 
   }
 }
 
-template int launch_stock_id<MPE_TU_T, true, false>(SmallId, const KParams<MPE_TU_T> &, bool, hipStream_t);
-template int launch_stock_id<MPE_TU_T, false, true>(SmallId, const KParams<MPE_TU_T> &, bool, hipStream_t);
-template int launch_stock_id<MPE_TU_T, true, true>(SmallId, const KParams<MPE_TU_T> &, bool, hipStream_t);
+template int launch_stock_id<MPE_TU_T, true, false>(SmallId, const KParams<MPE_TU_T> &, bool, bool, hipStream_t);
+template int launch_stock_id<MPE_TU_T, false, true>(SmallId, const KParams<MPE_TU_T> &, bool, bool, hipStream_t);
+template int launch_stock_id<MPE_TU_T, true, true>(SmallId, const KParams<MPE_TU_T> &, bool, bool, hipStream_t);
 
 }  // namespace mpe

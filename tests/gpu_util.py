@@ -13,16 +13,22 @@ from tests.gpu_util_host import desc_from_spec  # noqa: E402,F401
 
 
 class _Mode:
-    force_tile = 0          # MPE_FLAG_FORCE_TILE on every HipSim call (set by the tests' force_tile fixtures)
+    flags = 0               # mpe_buffers.flags on every HipSim call (set by the tests' kernel-selection fixtures)
+
+
+def set_call_flags(flags):
+    """Per-call kernel-selection flags (include/mpe_hip.h MPE_FLAG_*): FORCE_TILE routes the stock worlds through the
+    generic LDS-tile kernel; WIDE / SPLIT pick the one-env-per-lane / one-agent-per-wavefront register kernel of
+    simple_tag and simple_spread whatever the batch size."""
+    _Mode.flags = int(flags)
 
 
 def set_force_tile(on):
-    """Per-call flag (mpe_buffers.flags) that routes the stock worlds through the generic LDS-tile kernel."""
-    _Mode.force_tile = int(bool(on))
+    set_call_flags(_hip.FLAG_FORCE_TILE if on else 0)
 
 
 def call_flags():
-    return _hip.FLAG_FORCE_TILE if _Mode.force_tile else 0
+    return _Mode.flags
 
 
 def stats_rows(desc, B, dtype_bytes):

@@ -18,7 +18,7 @@ from oracle import mpe_oracle as O
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_force_tile, stats_rows
+    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_call_flags, set_force_tile, stats_rows
 
 F64_TOL = 1e-9
 
@@ -43,11 +43,14 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + '.npz'))
 
 
-@pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
+# every test that takes this fixture runs on each kernel that can serve the world: the one-env-per-lane register kernel
+# (MPE_FLAG_WIDE), the one-agent-per-wavefront form of simple_tag / simple_spread (MPE_FLAG_SPLIT; other worlds: the
+# same kernel as WIDE) and the generic LDS-tile kernel (MPE_FLAG_FORCE_TILE)
+@pytest.fixture(params=[2, 4, 1], ids=['wide_kernel', 'split_kernel', 'tile_kernel'])
 def force_tile(request):
-    set_force_tile(request.param)
+    set_call_flags(request.param)
     yield request.param
-    set_force_tile(0)
+    set_call_flags(0)
 
 
 def _maxerr(got, want):
@@ -157,7 +160,8 @@ def test_split_entry_points_equal_fused(mk, dtype, force_tile):
                                 lambda: O.simple_adversary_spec(), lambda: O.simple_push_spec()],
                          ids=['tag', 'spread', 'simple', 'adversary', 'push'])
 def test_small_and_tile_kernels_bit_identical(mk):
-    """The register kernel and the LDS-tile kernel implement the same operation order."""
+    """The register kernels (one env per lane; one agent per wavefront) and the LDS-tile kernel implement the same
+    operation order."""
     spec = mk()
     B = 4096 + 11
     rng = np.random.RandomState(2)
@@ -166,16 +170,17 @@ def test_small_and_tile_kernels_bit_identical(mk):
     for dtype in (torch.float64, torch.float32):
         act = dev(rng.rand(spec.n_agents, 5, B), dtype)
         res = []
-        for ft in (0, 1):
-            set_force_tile(ft)
+        for flags in (2, 4, 1):          # wide, split (tag / spread only), tile
+            set_call_flags(flags)
             sim = HipSim(spec, B, dtype)
             sim.set_state(pos, vel, np.arange(B) % max(spec.n_landmarks, 1))
             for _ in range(5):
                 sim.env_step(act)
             res.append(sim.host())
-        set_force_tile(0)
-        for x, y in zip(*res):
-            assert np.array_equal(x, y, equal_nan=True)
+        set_call_flags(0)
+        for other in res[1:]:
+            for x, y in zip(res[0], other):
+                assert np.array_equal(x, y, equal_nan=True)
 
 
 def test_config2_simple_spread_65536_f64_vs_oracle():
