@@ -8,9 +8,9 @@
 // rows env_step reads next), so an acting step moves 4 (in + out) bytes per env and nothing else.  One env per
 // lane: the 64 hidden activations live in VGPRs, the weights are wave-uniform and come through the scalar
 // cache (s_load -> SGPR operand of v_fmac), so the inner loops are pure VALU: 2 (in 64 + 64 64 + 64 out) flop
-// per env.  Dense but tiny: at 64 units the whole problem is 11 GFLOP per million envs -- f32 VALU work for
-// ~0.1 ms, not worth an MFMA tiling (fp32 MFMA has the vector rate anyway); f32 because the reference's
-// networks are.  Packed weights (host side, marl_amd/maddpg.py:pack_actor): W1t [in][64], b1 [64], W2t [64][64],
+// per env.  f32 because the reference's networks are.  This vector form is MPE_ACTOR_VALU; the default (MPE_ACTOR_AUTO)
+// is the matrix-core form further down, which reaches the same accuracy from split bf16 operands.
+// Packed weights (host side, marl_amd/maddpg.py:pack_actor): W1t [in][64], b1 [64], W2t [64][64],
 // b2 [64], W3t [64][16], b3 [16], output columns beyond s0 + s1 zero.
 #pragma once
 #include "mpe_device.h"
@@ -157,32 +157,106 @@ __global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// The same actor on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, so the
-// precision of the vector kernel).  MI355X_MICROARCH.md measures f32 MFMA at 155 TFLOP/s sustained against 52 for a
-// v_pk_fma_f32 GEMM, so round 1's "MFMA buys nothing" needed a measurement.  Measured (r2, 1 Mi envs, 16 -> 64 -> 64 -> 5,
-// tools/actor_bench.py): this kernel 170.8 us (88 TFLOP/s executed = 0.56 of the f32 matrix peak, 14 % of it in the
-// padded logits tile), the vector kernel above 158.1 us (73.6 TFLOP/s): a tie, the vector kernel stays the default
-// (MPE_ACTOR_AUTO); this one is selectable (MPE_ACTOR_MFMA) and tested the same way.
+// The same actor on the matrix cores, at f32 accuracy from bf16 MFMAs ("bf16x6").
+//
+// f32 MFMA has the vector rate (v_mfma_f32_32x32x2_f32: 256 flop / cycle / CU, the same as v_pk_fma_f32): round 2's first
+// matrix-core form, built on it, tied with the vector kernel above (170.8 vs 158.1 us per agent at 1 Mi envs).  The bf16
+// MFMA is 16x faster per k (v_mfma_f32_32x32x16_bf16: 32 cycles for 16 k), so every f32 operand is split EXACTLY into
+// three bf16 pieces, x = hi + mid + lo (the next 8 significant bits each: truncation, so the residuals are exact and
+// the range is f32's), and a product is the six partial products whose weight is >= 2^-16 of the leading one:
+//     x w = hi hi + hi mid + mid hi + mid mid + hi lo + lo hi        (+ mid lo + lo mid + lo lo < 2^-23 |x w|, dropped)
+// Each partial product is exact in the f32 accumulator (8 x 8 bits), so the result carries the error of an f32 dot
+// product (tests: <= 1e-5 against PyTorch f32, the vector kernel's bar).  Six MFMAs of 32 cycles replace eight of 64.
+// Measured (r2 MI355X, tools/actor_bench.py, 16 -> 64 -> 64 -> 5): 1 Mi envs 91.5 us vs 161.6 us for the vector kernel
+// (34 inputs: 127.0 vs 228.6), 262 144 envs 25.7 vs 43.9, 4 096 envs 11.9 vs 20.1 (the vector kernel's floor is its
+// 5 000-FMA dependent chain per lane).  What bounds it now is vector ISSUE, not the matrix pipe: per 32-env tile 84 MFMAs
+// (2 688 matrix-pipe cycles, 8 issue cycles each) beside ~860 vector instructions -- the operand splits (5.5 per value:
+// and, subtract, and, subtract, 1.5 permutes), relu as an integer max, Philox, the softmax; SQ counters: vector issue
+// 62 % + MFMA issue 11 % of the SIMD cycles.  Accumulators stay in VGPRs (-mllvm -amdgpu-mfma-vgpr-form in the Makefile:
+// no v_accvgpr_read per value, 160 + 64 -> 129 registers = 3 wavefronts per SIMD).
 //
 // Transposed formulation, envs on the N (lane) axis:  H1^T = W1^T X^T,  H2^T = W2^T H1^T,  Y^T = W3^T H2^T.
-// A tile is 32 envs.  D[row = hidden unit][col = env]: lane (n = l & 31, h = l >> 5) holds column n, register r holds row
-// (r & 3) + 8 (r >> 2) + 4 h  -- exactly the B-operand shape of the NEXT layer's k-step r (B[k = h][n]), with the k pair
-// (row(r, 0), row(r, 0) + 4): an accumulator register feeds the next MFMA as it is, no LDS, no lane movement; the A
-// operand (weights) is fetched to match: lane (m, h) of k-step r supplies W[in = 32 kt + row(r, h)][out = 32 mt + m].
-// W2 / W3 fragments stay in registers for all the wavefront's tiles (96 VGPRs), W1 / observations stream per tile.
-// Per tile: 2 ceil(in/2) + 64 + 32 MFMAs of 64 cycles; the 16 unused rows of the logits tile are the waste (14 %).
+// A tile is 32 envs.  D[row = unit][col = env]: lane (n = l & 31, h = l >> 5) holds column n, register r holds row
+// (r & 3) + 8 (r >> 2) + 4 h.  A k-block of the next layer is 16 consecutive units = accumulator registers 8 b .. 8 b + 7
+// of both lane halves, and the MFMA sums over k in any order as long as A and B agree on it: B slot (h, j) of k-block b
+// is register 8 (b & 1) + j of tile b >> 1 as it stands (relu, split, pack: no LDS, no lane movement), and the A operand
+// is fetched to match: slot (h, j) of lane (m, h) is W[16 b + (j & 3) + 8 (j >> 2) + 4 h][m].  The pre-split fragments
+// of W1 (up to 64 inputs), W2 and W3 sit in LDS (60 KiB; one conflict-free ds_read_b128 per piece): resident in
+// registers, W2 alone is 96 VGPRs and leaves no room to fetch the next tile's observations ahead.
 // The relaxed sample's noise comes from the same Philox words as in the vector kernel (word group q = row / 4).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int O>  // logits rows evaluated in the epilogue: 8 or 16
+// Eight f32 values -> three packed-bf16 operands (slot j = element j).  hi / mid / lo are the upper 16 bits of x, of
+// x - hi and of x - hi - mid: both subtractions are exact, and so is the sum of the three pieces.
+struct Bf16x3 {
+  u32x4 hi, mid, lo;
+};
+__device__ __forceinline__ Bf16x3 split_bf16x3(const float (&x)[8]) {
+  Bf16x3 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // (plain subtractions: packed v_pk_add_f32 is an anti-lever beside MFMAs, MI355X_MICROARCH.md cycle constants)
+    const uint32_t a0 = __float_as_uint(x[2 * i]), a1 = __float_as_uint(x[2 * i + 1]);
+    const float r0 = x[2 * i] - __uint_as_float(a0 & 0xFFFF0000u), r1 = x[2 * i + 1] - __uint_as_float(a1 & 0xFFFF0000u);
+    const uint32_t b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(b0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+    o.hi[i] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);  // (upper half of a1) : (upper half of a0)
+    o.mid[i] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    o.lo[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+  return o;
+}
+// max(x, 0) in one instruction: as signed integers, negative floats (and -0) are below 0 and positive floats keep
+// their order (fmaxf costs a second instruction that quiets signalling NaNs; a NaN stays a NaN here if its sign is +)
+__device__ __forceinline__ float relu1(float x) {
+  const int i = (int)__float_as_uint(x);
+  return __uint_as_float((uint32_t)(i > 0 ? i : 0));
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// c += A B at f32 accuracy: smallest partial products first
+__device__ __forceinline__ f32x16 mfma_bf16x6(const Bf16x3 &a, const Bf16x3 &b, f32x16 c) {
+  c = mfma_bf16(a.lo, b.hi, c);
+  c = mfma_bf16(a.hi, b.lo, c);
+  c = mfma_bf16(a.mid, b.mid, c);
+  c = mfma_bf16(a.mid, b.hi, c);
+  c = mfma_bf16(a.hi, b.mid, c);
+  return mfma_bf16(a.hi, b.hi, c);
+}
+
+// A fragment of a [K][ncols] row-major weight matrix for output column `col` (< 0: a zero column): slot j takes row k_of(j)
+template <typename KOf>
+__device__ __forceinline__ Bf16x3 weight_fragment(const float *__restrict__ W, int K, int ncols, int col, KOf k_of) {
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k_of(j);
+    w[j] = (col >= 0 && k < K) ? W[(int64_t)k * ncols + col] : 0.0f;
+  }
+  return split_bf16x3(w);
+}
+
+constexpr int kActorLdsInputs = 64;  // W1 rows kept pre-split in LDS; inputs beyond that are split per tile
+
+// O: logits rows evaluated in the epilogue, 8 or 16.  NKB: k-blocks of 16 observation rows, 1..3 compiled in (the tile
+// loop is then one straight block: next tile's rows fetched ahead, LDS reads scheduled across the MFMAs), 0 = any width.
+template <int O, int NKB>
 __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, const ActorJobs jobs,
                                                          uint32_t counter, uint64_t env_id0, int tiles_per_wave) {
   constexpr int H = kActorHidden, OP = kActorMaxOut;
   static_assert(H == 64 && OP == 16, "two 32-row tiles of hidden units, one (half-used) tile of logits");
+  constexpr int NKB1 = NKB > 0 ? NKB : kActorLdsInputs / 16;  // W1 k-blocks held in LDS
   __shared__ __align__(16) float sBias[2 * H + 32];  // b1 | b2 | b3 padded with zeros to 32 rows
+  __shared__ u32x4 sW1[2 * NKB1 * 3][64];             // [(mt, kb), piece][lane]
+  __shared__ u32x4 sW2[2 * 4 * 3][64];                // [(mt, kb), piece][lane]
+  __shared__ u32x4 sW3[4 * 3][64];                    // [kb, piece][lane]
   const ActorJob &job = jobs.j[blockIdx.y];
   const float *__restrict__ obs = job.obs, *__restrict__ wts = job.wts, *__restrict__ u = job.u;
   float *__restrict__ act = job.act;
@@ -195,28 +269,82 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
     sBias[threadIdx.x] = threadIdx.x < H ? b1[threadIdx.x]
                                           : (threadIdx.x < 2 * H ? b2[threadIdx.x - H]
                                                                  : (threadIdx.x - 2 * H < OP ? b3[threadIdx.x - 2 * H] : 0.0f));
-  // resident A fragments: W2 as [mt][kt][r], W3 as [kt][r]
-  float a2[2][2][16], a3[2][16];
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = 32 * kt + mfma_row(r, h);
-      a2[0][kt][r] = W2[k * H + n];
-      a2[1][kt][r] = W2[k * H + 32 + n];
-      a3[kt][r] = n < OP ? W3[k * OP + n] : 0.0f;
+  const int nkb1 = NKB > 0 ? NKB : (in_dim + 15) / 16;
+  auto k_in = [&](int kb) { return [=](int j) { return 16 * kb + 8 * h + j; }; };                   // layer 1: natural order
+  auto k_acc = [&](int kb) { return [=](int j) { return 16 * kb + (j & 3) + 8 * (j >> 2) + 4 * h; }; };  // layers 2, 3
+  for (int f = wave; f < 2 * NKB1; f += 4) {  // W1 fragments (mt = f & 1, kb = f >> 1) of the first 64 inputs
+    const int kb = f >> 1;
+    if (kb < nkb1) {
+      const Bf16x3 a = weight_fragment(W1, in_dim, H, 32 * (f & 1) + n, k_in(kb));
+      sW1[3 * f + 0][lane] = a.hi;
+      sW1[3 * f + 1][lane] = a.mid;
+      sW1[3 * f + 2][lane] = a.lo;
     }
+  }
+  {  // W3 fragment of k-block `wave`
+    const Bf16x3 a = weight_fragment(W3, H, OP, n < OP ? n : -1, k_acc(wave));
+    sW3[3 * wave + 0][lane] = a.hi;
+    sW3[3 * wave + 1][lane] = a.mid;
+    sW3[3 * wave + 2][lane] = a.lo;
+  }
+  for (int f = wave; f < 8; f += 4) {  // W2 fragments (mt = f & 1, kb = f >> 1)
+    const Bf16x3 a = weight_fragment(W2, H, H, 32 * (f & 1) + n, k_acc(f >> 1));
+    sW2[3 * f + 0][lane] = a.hi;
+    sW2[3 * f + 1][lane] = a.mid;
+    sW2[3 * f + 2][lane] = a.lo;
+  }
   __syncthreads();
+  // Observation rows of k-block kb for the tile at env e0: B slot (h, j) is row 16 kb + 8 h + j.  Rows beyond in_dim
+  // meet zero weight rows; they read row 0 (a finite observation x 0, where the vector kernel reads nothing).
+  // NKB > 0: the row offsets are per-lane constants (32-bit byte offsets: the host checks in_dim ld_obs < 2^30) on a
+  // wave-uniform tile base; lanes of the last tile that lie beyond B step back to env B - 1.
+  constexpr int PFA = NKB > 0 ? NKB : 1;
+  uint32_t roff[PFA][8];
+#pragma unroll
+  for (int kb = 0; kb < PFA; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * kb + 8 * h + j;
+      roff[kb][j] = (uint32_t)(((int64_t)(k < in_dim ? k : 0) * ld_obs + n) * 4);
+    }
+  auto load_obs = [&](int kb, int64_t e0, float (&x)[8]) {
+    if (NKB > 0) {
+      const char *base = reinterpret_cast<const char *>(obs + e0);  // wave-uniform
+      const int64_t over = e0 + n - (B - 1);
+      const uint32_t back = over > 0 ? (uint32_t)over * 4u : 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = ld_stream(reinterpret_cast<const float *>(base + (roff[kb < PFA ? kb : 0][j] - back)));
+    } else {
+      const int64_t e = e0 + n < B ? e0 + n : B - 1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * kb + 8 * h + j;
+        x[j] = ld_stream(obs + (int64_t)(k < in_dim ? k : 0) * ld_obs + e);
+      }
+    }
+  };
+  // The first PF k-blocks of the NEXT tile are fetched while this one is computed: with two wavefronts per SIMD and
+  // ~3 500 cycles of work per tile, an exposed HBM round trip per tile would cost about as much again.
+  constexpr int PF = NKB;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+  float xc[PFA][8], xn[PFA][8];
+  if (tile0 * 32 < B) {
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb)
+      if (kb < nkb1) load_obs(kb, tile0 * 32, xc[kb]);
+  }
   for (int t = 0; t < tiles_per_wave; ++t) {
     const int64_t e0 = (tile0 + t) * 32;
     if (e0 >= B) break;  // wave-uniform
     const int64_t env = e0 + n;
     const bool active = env < B;
     const int64_t ge = active ? env : B - 1;  // tail lanes shadow the last env, their stores are skipped
-    // ---- layer 1: acc1[mt] = b1 + W1^T X^T, k-steps of (2 s, 2 s + 1), eight at a time so the loads are batched.
-    // (Fetching the next tile's first batch ahead of layers 2 and 3 was tried: 165.4 vs 170.8 us at 16 inputs, but 256
-    // VGPRs and 24 % slower at 34 inputs; the two wavefronts per SIMD already cover each other's load waits.)
+    if (t + 1 < tiles_per_wave && e0 + 32 < B) {
+#pragma unroll
+      for (int kb = 0; kb < PF; ++kb)
+        if (kb < nkb1) load_obs(kb, e0 + 32, xn[kb]);
+    }
+    // ---- layer 1: acc1[mt] = b1 + W1^T X^T
     f32x16 acc1[2], acc2[2], acc3;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -228,25 +356,29 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
         acc1[1][4 * g + q] = c1[q];
       }
     }
-    for (int sb = 0; sb < in_dim; sb += 16) {
-      float xb[8], wa[8], wb[8];
+    auto layer1_block = [&](int kb, const float (&x)[8]) {
+      const Bf16x3 b = split_bf16x3(x);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int k = sb + 2 * s + h;
-        const bool ok = k < in_dim;
-        const int kk = ok ? k : 0;
-        const float x = ld_stream(obs + (int64_t)kk * ld_obs + ge);
-        xb[s] = ok ? x : 0.0f;
-        wa[s] = W1[kk * H + n];
-        wb[s] = W1[kk * H + 32 + n];
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        if (sb + 2 * s < in_dim) {  // wave-uniform: a step with both k beyond the input is skipped
-          acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], xb[s], acc1[0], 0, 0, 0);
-          acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[s], xb[s], acc1[1], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt) {
+        Bf16x3 a;
+        if (kb < NKB1) {  // wave-uniform
+          const int f = 2 * kb + mt;
+          a.hi = sW1[3 * f + 0][lane];
+          a.mid = sW1[3 * f + 1][lane];
+          a.lo = sW1[3 * f + 2][lane];
+        } else {
+          a = weight_fragment(W1, in_dim, H, 32 * mt + n, k_in(kb));
         }
+        acc1[mt] = mfma_bf16x6(a, b, acc1[mt]);
       }
+    };
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb)
+      if (kb < nkb1) layer1_block(kb, xc[kb]);
+    for (int kb = PF; kb < nkb1; ++kb) {  // wide observations: the rest is fetched here
+      float x[8];
+      load_obs(kb, e0, x);
+      layer1_block(kb, x);
     }
     // ---- layer 2: relu(acc1) registers are the B operands
 #pragma unroll
@@ -260,13 +392,21 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
       }
     }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kb = 0; kb < 4; ++kb) {
+      float x[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float b = fmaxf(acc1[kt][r], 0.0f);
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][kt][r], b, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][kt][r], b, acc2[1], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) x[j] = relu1(acc1[kb >> 1][8 * (kb & 1) + j]);
+      const Bf16x3 b = split_bf16x3(x);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int f = 2 * kb + mt;
+        Bf16x3 a;
+        a.hi = sW2[3 * f + 0][lane];
+        a.mid = sW2[3 * f + 1][lane];
+        a.lo = sW2[3 * f + 2][lane];
+        acc2[mt] = mfma_bf16x6(a, b, acc2[mt]);
       }
+    }
     // ---- layer 3: one tile of logits (rows >= 16 are padding)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -275,10 +415,17 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
       for (int q = 0; q < 4; ++q) acc3[4 * g + q] = c0[q];
     }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kb = 0; kb < 4; ++kb) {
+      float x[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[kt][r], fmaxf(acc2[kt][r], 0.0f), acc3, 0, 0, 0);
+      for (int j = 0; j < 8; ++j) x[j] = relu1(acc2[kb >> 1][8 * (kb & 1) + j]);
+      const Bf16x3 b = split_bf16x3(x);
+      Bf16x3 a;
+      a.hi = sW3[3 * kb + 0][lane];
+      a.mid = sW3[3 * kb + 1][lane];
+      a.lo = sW3[3 * kb + 2][lane];
+      acc3 = mfma_bf16x6(a, b, acc3);
+    }
     // ---- Gumbel-softmax per sub-space; this lane holds logits rows mfma_row(r, h), r < O / 2, of env n
     constexpr int R = O / 2;
     float lg[R];
@@ -327,6 +474,10 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
         if (m < nout) st_stream(act + (int64_t)m * ld_act + env, lg[r] * (m < s0 ? r0 : r1));
       }
     }
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xc[kb][j] = xn[kb][j];
   }
 }
 

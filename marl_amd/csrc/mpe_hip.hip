@@ -1027,7 +1027,7 @@ extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs
                           j.in_dim, j.s0, j.s1, (uint32_t)j.seed, (uint32_t)(j.seed >> 32)};
       wide = wide || j.s0 + j.s1 > 8;
     }
-    if (kernel != MPE_ACTOR_MFMA) {  // MPE_ACTOR_AUTO: the vector kernel (faster by 3-8 % on MI355X, mpe_actor_kernel.h)
+    if (kernel == MPE_ACTOR_VALU) {  // MPE_ACTOR_AUTO: the matrix-core kernel (1.6-2.5x the vector kernel from 1 Ki to 1 Mi envs)
       const dim3 grid((unsigned)((B + 255) / 256), (unsigned)nj), block(256);
       auto kern = wide ? actor_forward_kernel<16> : actor_forward_kernel<8>;
       hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, tab, call_counter, env_id0);
@@ -1038,8 +1038,17 @@ extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs
       int tpw = 8;
       while (tpw > 1 && tiles / (4 * tpw) < 1024 / nj) tpw >>= 1;
       const dim3 grid((unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)), (unsigned)nj), block(256);
-      auto kern = wide ? actor_mfma_kernel<16> : actor_mfma_kernel<8>;
-      hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, tab, call_counter, env_id0, tpw);
+      // one instantiation per observation width in k-blocks of 16 rows (all jobs of the launch alike), else the generic one
+      int nkb = (tab.j[0].in_dim + 15) / 16;
+      for (int i = 1; i < nj; ++i)
+        if ((tab.j[i].in_dim + 15) / 16 != nkb) nkb = 0;
+      if (nkb > 3 || (int64_t)48 * ld_obs >= ((int64_t)1 << 30)) nkb = 0;  // 32-bit row offsets inside the kernel
+      using Kern = void (*)(int64_t, int64_t, int64_t, const ActorJobs, uint32_t, uint64_t, int);
+      static const Kern kerns[2][4] = {
+          {actor_mfma_kernel<8, 0>, actor_mfma_kernel<8, 1>, actor_mfma_kernel<8, 2>, actor_mfma_kernel<8, 3>},
+          {actor_mfma_kernel<16, 0>, actor_mfma_kernel<16, 1>, actor_mfma_kernel<16, 2>, actor_mfma_kernel<16, 3>}};
+      hipLaunchKernelGGL(kerns[wide][nkb], grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, tab, call_counter,
+                         env_id0, tpw);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

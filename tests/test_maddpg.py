@@ -241,7 +241,7 @@ def test_fused_actor_extreme_uniforms_and_sharded_noise():
     # the vector kernel and the matrix-core kernel draw the same noise: equal up to the summation order of the dot products
     a1 = maddpg.actor_forward(packed, rows2[:, :B2].t(), sizes, seed=3, call_counter=9, env_id0=1000, kernel=1)
     a2 = maddpg.actor_forward(packed, rows2[:, :B2].t(), sizes, seed=3, call_counter=9, env_id0=1000, kernel=2)
-    assert float((a1 - a2).abs().max()) <= 1e-5 and torch.equal(whole, a1)      # AUTO = the vector kernel
+    assert float((a1 - a2).abs().max()) <= 1e-5 and torch.equal(whole, a2)      # AUTO = the matrix-core kernel
 
 
 @pytest.mark.gpu

@@ -12,12 +12,13 @@ from marl_amd.maddpg import actor_forward, mlp_model, pack_actor  # noqa: E402
 
 
 def main():
-    B, ld = 1 << 20, (1 << 20) + 256
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    ld = B + 256
     for in_dim, sizes in ((16, [5]), (34, [5, 4]), (28, [5, 7])):
         net = mlp_model(in_dim, sum(sizes)).cuda()
         packed = pack_actor(net)
         obs = torch.randn(in_dim, ld, device='cuda')[:, :B].t()
-        for kernel, name in ((1, 'vector FMA'), (2, 'f32 MFMA')):
+        for kernel, name in ((1, 'vector FMA'), (2, 'bf16x6 MFMA')):
             for c in range(3):
                 actor_forward(packed, obs, sizes, seed=1, call_counter=c, kernel=kernel)
             torch.cuda.synchronize()
@@ -29,7 +30,7 @@ def main():
             torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / 20 * 1e-3
             flop = 2.0 * B * (in_dim * 64 + 64 * 64 + 64 * sum(sizes))   # useful flop (the kernels evaluate 8 / 16 / 32 columns)
-            print('actor %3d -> 64 -> 64 -> %-7s %d envs, %-10s: %7.1f us  %5.1f useful TFLOP/s f32  %5.0f GB/s' %
+            print('actor %3d -> 64 -> 64 -> %-7s %d envs, %-12s: %7.1f us  %5.1f useful TFLOP/s f32  %5.0f GB/s' %
                   (in_dim, sizes, B, name, t * 1e6, flop / t / 1e12, 4.0 * B * (in_dim + sum(sizes)) / t / 1e9))
 
 
