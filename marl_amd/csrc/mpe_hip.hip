@@ -736,8 +736,8 @@ __global__ __launch_bounds__(256) void replay_add_kernel(int64_t capacity, int64
 // consecutive transitions are consecutive ring rows the tile is one contiguous span of the ring (except at
 // the wrap): stored with a flat index, every lane busy whatever the record width.  TW = 256 (each wavefront
 // loads its own 64 transitions, so a workgroup reads 1 KiB of every source row, like the env kernels) when
-// the tile fits 64 KiB of LDS, else TW = 64 (the four wavefronts share the columns).  Measured with
-// simple_tag's 39-column records, 1 Mi transitions, f32: the store phase alone 60 us with plain stores.
+// the tile fits 64 KiB of LDS: that case runs replay_add_multi_kernel below (its tuned form) with one job; this
+// kernel is left with TW = 64 (the four wavefronts share the columns) for wider records.
 constexpr int kReplayFlatCols = 160;
 template <typename T, int TW>
 __global__ __launch_bounds__(256) void replay_add_flat_kernel(int64_t capacity, int64_t next_idx, int64_t n, int64_t skip,
@@ -804,20 +804,30 @@ __global__ __launch_bounds__(256) void replay_add_multi_kernel(int64_t n, const 
   const int64_t e0 = jobs.skip[jb] + (int64_t)blockIdx.x * TW;
   if (e0 >= n) return;  // workgroup-uniform: this buffer keeps fewer transitions than the widest job
   const int ne = (int)(n - e0 < TW ? n - e0 : TW);
-  constexpr int kU = 10;
+  // Where each record column comes from, worked out once per workgroup: searching the segment table in front of every
+  // load (a chain of dependent scalar loads) paced the loads -- the read side alone took the kernel's whole 92 us.
+  __shared__ const T *s_src[kReplayFlatCols];
+  __shared__ int64_t s_es[kReplayFlatCols];
+  if ((int)threadIdx.x < width) {
+    const int c = threadIdx.x;
+    int s = 0;
+    while (c >= sg.row0[s + 1]) ++s;
+    s_src[c] = (const T *)sg.ptr[s] + (int64_t)(c - sg.row0[s]) * sg.row_stride[s] + e0 * sg.env_stride[s];
+    s_es[c] = sg.env_stride[s];
+  }
+  __syncthreads();
+  constexpr int kU = 40;  // row loads in flight per lane (1 Mi x 39 columns f32: 10 -> 71.5 us, 20 -> 63.6, 40 -> 61.4)
   const int el = 64 * w + lane;
-  for (int c0 = 0; c0 < width; c0 += kU) {
+  const int elc = el < ne ? el : ne - 1;  // lanes / columns beyond the tile re-read its last element: no branch per load,
+  for (int c0 = 0; c0 < width; c0 += kU) {  // so a batch is 20 table reads, one wait, 20 loads in flight
     T v[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const int c = c0 + u;
-      v[u] = T(0);
-      if (c < width && el < ne) {
-        int s = 0;
-        while (c >= sg.row0[s + 1]) ++s;
-        const T *src = (const T *)sg.ptr[s];
-        v[u] = ld_stream(src + (int64_t)(c - sg.row0[s]) * sg.row_stride[s] + (e0 + el) * sg.env_stride[s]);
-      }
+      const int c = c0 + u < width ? c0 + u : width - 1;
+      // (a pointer read back from LDS has lost its address space: say it is global, or the loads become FLAT ones,
+      // which every LDS wait then waits for as well -- one load in flight per wavefront)
+      typedef const T __attribute__((address_space(1))) * gptr;
+      v[u] = __builtin_nontemporal_load((gptr)(uintptr_t)s_src[c] + elc * s_es[c]);
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u)
@@ -827,8 +837,40 @@ __global__ __launch_bounds__(256) void replay_add_multi_kernel(int64_t n, const 
   const int total = ne * width;
   T *ring = jobs.ring[jb];
   const int64_t r0 = (jobs.next_idx[jb] + e0) % capacity;
+  // element f = e * width + c of the workgroup's contiguous run of records.  f < 2^16 and width < 2^16, so
+  // f / width == umulhi(f, floor(2^32 / width) + 1) exactly: no division per element, and the trips stay independent
+  // (carrying (e, c) from trip to trip instead serialises the LDS reads: 99.6 vs 93 us per 1 Mi x 39 append)
+  const uint32_t inv = (uint32_t)(0x100000000ull / (uint32_t)width) + 1u;
+  // the run is contiguous in the ring unless it wraps: four consecutive elements per lane in one 16-byte store
+  // (any 4-byte alignment is legal for global_store_dwordx4), the last total % 4 elements one by one
+  const bool wraps = r0 + ne > capacity;
+  if (sizeof(T) == 4 && !wraps) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    T *run = ring + r0 * width;
+    const int nq = total >> 2;
+#pragma unroll 2
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      int e = (int)__umulhi((uint32_t)(4 * q), inv), c = 4 * q - e * width;
+      f4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = (float)tile[c * LDT + e];
+        if (++c == width) {
+          c = 0;
+          ++e;
+        }
+      }
+      __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(run + 4 * q));
+    }
+    for (int f = 4 * nq + threadIdx.x; f < total; f += 256) {
+      const int e = (int)__umulhi((uint32_t)f, inv), c = f - e * width;
+      st_stream(run + f, tile[c * LDT + e]);
+    }
+    return;
+  }
+#pragma unroll 4
   for (int f = threadIdx.x; f < total; f += 256) {
-    const int e = f / width, c = f - e * width;
+    const int e = (int)__umulhi((uint32_t)f, inv), c = f - e * width;
     int64_t r = r0 + e;
     r = r >= capacity ? r - capacity : r;
     st_stream(ring + r * width + c, tile[c * LDT + e]);
@@ -892,9 +934,16 @@ static int replay_add_impl(int64_t capacity, int64_t next_idx, int64_t n, int wi
   if (width <= kReplayFlatCols) {
     const size_t lds256 = (size_t)width * 257 * sizeof(T), lds64 = (size_t)width * 65 * sizeof(T);
     if (lds256 <= 64 * 1024 && n - skip >= 256) {
-      const dim3 grid((unsigned)((n - skip + 255) / 256));
-      hipLaunchKernelGGL((replay_add_flat_kernel<T, 256>), grid, block, lds256, (hipStream_t)stream, capacity, next_idx,
-                         n, skip, width, sg, (T *)ring);
+      // the one-launch-for-several-buffers kernel with a single job (it is the tuned form of the TW = 256 tile)
+      ReplayJobs<T> tab{};
+      tab.sg[0] = sg;
+      tab.capacity[0] = capacity;
+      tab.next_idx[0] = next_idx;
+      tab.skip[0] = skip;
+      tab.ring[0] = (T *)ring;
+      tab.width[0] = width;
+      const dim3 grid((unsigned)((n - skip + 255) / 256), 1u);
+      hipLaunchKernelGGL(replay_add_multi_kernel<T>, grid, block, lds256, (hipStream_t)stream, n, tab);
     } else {
       const dim3 grid((unsigned)((n - skip + 63) / 64));
       if (lds64 > 64 * 1024) {
