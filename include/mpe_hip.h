@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 6
+#define MPE_ABI_VERSION 7
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -333,6 +333,16 @@ typedef struct mpe_replay_job {
 } mpe_replay_job;
 int mpe_replay_add_multi_f32(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream);
 int mpe_replay_add_multi_f64(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream);
+/* The same with the moving part of every ring cursor in device memory: job i appends at
+ * (jobs[i].next_idx + *cursors[i]) % capacity (cursors[i] may be NULL = 0; cursors itself is a host array of n_jobs
+ * device pointers, read during the call).  No counterpart in the reference: a launch recorded in a HIP graph bakes its
+ * arguments, so a replayed training loop (act -> step -> store, experiments/simple_train.py:257-300) keeps the words that
+ * change from replay to replay in memory.  Buffers the one-launch kernel does not cover (records wider than 63 f32 / 31 f64
+ * columns, fewer than 256 transitions) are refused with MPE_ERR_UNSUPPORTED when their cursor is not NULL. */
+int mpe_replay_add_multi_cur_f32(int n_jobs, const mpe_replay_job *jobs, const int64_t *const *cursors, int64_t n,
+                                 void *stream);
+int mpe_replay_add_multi_cur_f64(int n_jobs, const mpe_replay_job *jobs, const int64_t *const *cursors, int64_t n,
+                                 void *stream);
 int mpe_replay_gather_f32(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
                           void *out, void *stream);
 int mpe_replay_gather_f64(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
@@ -371,6 +381,11 @@ typedef struct mpe_actor_job {
                             products per product: the error of an f32 dot product; 32 envs per tile on the lane axis */
 int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs, int64_t ld_act,
                                 uint32_t call_counter, uint64_t env_id0, int kernel, void *stream);
+/* The same with a device word added to call_counter (counter_dev may be NULL = 0): for acting steps recorded in a HIP
+ * graph, see mpe_replay_add_multi_cur_*.  No counterpart in the reference. */
+int mpe_actor_forward_multi_ctr_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs, int64_t ld_act,
+                                    uint32_t call_counter, const uint32_t *counter_dev, uint64_t env_id0, int kernel,
+                                    void *stream);
 
 /*
  * Episode statistics (what the reference's loops sum on the host: rew_n per agent,

@@ -26,7 +26,7 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_FORCE_TILE = 1
 FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
 FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
@@ -147,6 +147,12 @@ def _load():
     L.mpe_actor_forward_f32.restype = ci
     L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]
     # n_jobs, jobs, B, ld_obs, ld_act, call_counter, env_id0, kernel (ACTOR_*), stream
+    L.mpe_actor_forward_multi_ctr_f32.restype = ci
+    L.mpe_actor_forward_multi_ctr_f32.argtypes = [ci, C.POINTER(ActorJob), i64, i64, i64, u32, vp, u64, ci, vp]
+    for suf in ('f32', 'f64'):
+        f = getattr(L, 'mpe_replay_add_multi_cur_' + suf)  # n_jobs, jobs, cursors (host array of device pointers), n, stream
+        f.restype = ci
+        f.argtypes = [ci, C.POINTER(ReplayJob), C.POINTER(vp), i64, vp]
     L.mpe_actor_forward_multi_f32.restype = ci
     L.mpe_actor_forward_multi_f32.argtypes = [ci, C.POINTER(ActorJob), i64, i64, i64, u32, u64, ci, vp]
     L.mpe_stats_rows.restype = i64

@@ -38,6 +38,9 @@ struct ActorJob {
 constexpr int kActorMaxJobs = 16;  // agents per launch (blockIdx.y); more agents = more launches
 struct ActorJobs {
   ActorJob j[kActorMaxJobs];
+  // optional device word added to the launch's call counter: a launch recorded in a HIP graph bakes its arguments,
+  // so a replayed acting step takes the part of the counter that moves from memory (mpe_actor_forward_multi_ctr_f32)
+  const uint32_t *counter_dev;
 };
 
 template <int O>  // output columns evaluated: 8 or 16 (>= s0 + s1 of every job); W3t / b3 keep their 16-column packing
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(256) MPE_ACTOR_ATTR void actor_forward_kernel(int64
                                                                            uint64_t env_id0) {
   // blockIdx.y = agent: every agent of the step in ONE launch (wave-uniform job fields -> scalar loads)
   const ActorJob &job = jobs.j[blockIdx.y];
+  if (jobs.counter_dev != nullptr) counter += *jobs.counter_dev;  // wave-uniform: a scalar load
   const float *__restrict__ obs = job.obs, *__restrict__ wts = job.wts, *__restrict__ u = job.u;
   float *__restrict__ act = job.act;
   const int in_dim = job.in_dim, s0 = job.s0, s1 = job.s1;
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
   __shared__ u32x4 sW2[2 * 4 * 3][64];                // [(mt, kb), piece][lane]
   __shared__ u32x4 sW3[4 * 3][64];                    // [kb, piece][lane]
   const ActorJob &job = jobs.j[blockIdx.y];
+  if (jobs.counter_dev != nullptr) counter += *jobs.counter_dev;  // wave-uniform: a scalar load
   const float *__restrict__ obs = job.obs, *__restrict__ wts = job.wts, *__restrict__ u = job.u;
   float *__restrict__ act = job.act;
   const int in_dim = job.in_dim, s0 = job.s0, nout = job.s0 + job.s1;

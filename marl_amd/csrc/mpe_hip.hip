@@ -790,6 +790,9 @@ struct ReplayJobs {
   int64_t capacity[kReplayMaxJobs], next_idx[kReplayMaxJobs], skip[kReplayMaxJobs];
   T *ring[kReplayMaxJobs];
   int32_t width[kReplayMaxJobs];
+  // optional device word added to next_idx (mod capacity): the part of the ring cursor that moves between replays of a
+  // HIP graph, whose launches bake their arguments (mpe_replay_add_multi_cur_*)
+  const int64_t *cursor[kReplayMaxJobs];
 };
 template <typename T>
 __global__ __launch_bounds__(256) void replay_add_multi_kernel(int64_t n, const ReplayJobs<T> jobs) {
@@ -836,7 +839,8 @@ __global__ __launch_bounds__(256) void replay_add_multi_kernel(int64_t n, const 
   __syncthreads();
   const int total = ne * width;
   T *ring = jobs.ring[jb];
-  const int64_t r0 = (jobs.next_idx[jb] + e0) % capacity;
+  const int64_t moved = jobs.cursor[jb] != nullptr ? *jobs.cursor[jb] % capacity : 0;  // workgroup-uniform
+  const int64_t r0 = (jobs.next_idx[jb] + moved + e0) % capacity;
   // element f = e * width + c of the workgroup's contiguous run of records.  f < 2^16 and width < 2^16, so
   // f / width == umulhi(f, floor(2^32 / width) + 1) exactly: no division per element, and the trips stay independent
   // (carrying (e, c) from trip to trip instead serialises the LDS reads: 99.6 vs 93 us per 1 Mi x 39 append)
@@ -984,7 +988,8 @@ static int replay_bind_segs(int nseg, const mpe_replay_seg *segs, ReplaySegs &sg
 }
 
 template <typename T>
-static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream) {
+static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, const int64_t *const *cursors, int64_t n,
+                                 void *stream) {
   if (!jobs) return MPE_ERR_NULL;
   if (n_jobs < 1 || n < 0) return MPE_ERR_ARG;
   for (int i = 0; i < n_jobs; ++i) {  // validate everything before the first launch
@@ -1014,12 +1019,14 @@ static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, int64_t
       tab.skip[nj] = skip;
       tab.ring[nj] = (T *)j.ring;
       tab.width[nj] = j.width;
+      tab.cursor[nj] = cursors ? cursors[i0 + nj] : nullptr;
       wmax = j.width > wmax ? j.width : wmax;
       keep_max = n - skip > keep_max ? n - skip : keep_max;
       ++nj;
     }
     if (nj == 0) {
       const mpe_replay_job &j = jobs[i0];
+      if (cursors && cursors[i0]) return MPE_ERR_UNSUPPORTED;  // the single-buffer kernels take no device cursor
       const int rc = replay_add_impl<T>(j.capacity, j.next_idx, n, j.width, j.nseg, j.segs, j.ring, stream);
       if (rc) return rc;
       ++i0;
@@ -1056,10 +1063,11 @@ static int actor_job_check(const mpe_actor_job *j) {
   return MPE_OK;
 }
 
-extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs,
-                                           int64_t ld_act, uint32_t call_counter, uint64_t env_id0, int kernel,
-                                           void *stream) {
+extern "C" int mpe_actor_forward_multi_ctr_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs,
+                                               int64_t ld_act, uint32_t call_counter, const uint32_t *counter_dev,
+                                               uint64_t env_id0, int kernel, void *stream) {
   if (!jobs) return MPE_ERR_NULL;
+  if (misaligned<uint32_t>(counter_dev)) return MPE_ERR_ALIGN;
   if (n_jobs < 1 || kernel < MPE_ACTOR_AUTO || kernel > MPE_ACTOR_MFMA) return MPE_ERR_ARG;
   if (B < 1 || ld_obs < B || ld_act < B) return MPE_ERR_BATCH;
   for (int i = 0; i < n_jobs; ++i) {
@@ -1069,6 +1077,7 @@ extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs
   for (int i0 = 0; i0 < n_jobs; i0 += kActorMaxJobs) {  // kActorMaxJobs agents per launch
     const int nj = n_jobs - i0 < kActorMaxJobs ? n_jobs - i0 : kActorMaxJobs;
     ActorJobs tab{};
+    tab.counter_dev = counter_dev;
     int wide = 0;
     for (int i = 0; i < nj; ++i) {
       const mpe_actor_job &j = jobs[i0 + i];
@@ -1103,6 +1112,12 @@ extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs
     if (e != hipSuccess) return (int)e;
   }
   return MPE_OK;
+}
+
+extern "C" int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs,
+                                           int64_t ld_act, uint32_t call_counter, uint64_t env_id0, int kernel,
+                                           void *stream) {
+  return mpe_actor_forward_multi_ctr_f32(n_jobs, jobs, B, ld_obs, ld_act, call_counter, nullptr, env_id0, kernel, stream);
 }
 
 extern "C" int mpe_actor_forward_f32(int64_t B, int64_t ld_obs, int64_t ld_act, int in_dim, int s0, int s1,
@@ -1227,7 +1242,14 @@ extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, 
     return replay_add_impl<T>(capacity, next_idx, n, width, nseg, segs, ring, stream);                         \
   }                                                                                                            \
   extern "C" int mpe_replay_add_multi_##SUF(int n_jobs, const mpe_replay_job *jobs, int64_t n, void *stream) { \
-    return replay_add_multi_impl<T>(n_jobs, jobs, n, stream);                                                  \
+    return replay_add_multi_impl<T>(n_jobs, jobs, nullptr, n, stream);                                         \
+  }                                                                                                            \
+  extern "C" int mpe_replay_add_multi_cur_##SUF(int n_jobs, const mpe_replay_job *jobs,                        \
+                                                const int64_t *const *cursors, int64_t n, void *stream) {      \
+    if (!cursors) return MPE_ERR_NULL;                                                                         \
+    for (int i = 0; i < n_jobs; ++i)                                                                           \
+      if (misaligned<int64_t>(cursors[i])) return MPE_ERR_ALIGN;                                               \
+    return replay_add_multi_impl<T>(n_jobs, jobs, cursors, n, stream);                                         \
   }                                                                                                            \
   extern "C" int mpe_replay_gather_##SUF(int64_t capacity, int width, const int64_t *idx, int64_t batch,       \
                                          const void *ring, void *out, void *stream) {                          \

@@ -23,6 +23,12 @@
 #include "mpe_device.h"
 #include "mpe_launch.h"
 
+#ifdef MPE_ABL_NO_STATS  // ablation: what the statistics rows cost
+#define MPE_TILE_WANT_STATS(x) false
+#else
+#define MPE_TILE_WANT_STATS(x) (x)
+#endif
+
 namespace mpe {
 
 // 16-byte vector of T: 4 floats / 2 doubles = the envs one lane covers in the vectorised observation phase
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
 
     if (DO_OBS) {
       const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr,
-                 want_stats = p.stats != nullptr;
+                 want_stats = MPE_TILE_WANT_STATS(p.stats != nullptr);
       double *srow = want_stats ? p.stats + (int64_t)blockIdx.x * (2 * A + 2) : nullptr;
       // goal landmark of this env (agent.goal_a), scenarios with a goal only
       const bool has_goal = kind_has_goal(kind);

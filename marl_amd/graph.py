@@ -67,3 +67,99 @@ class CapturedSteps(object):
         if self.env.info_callback is not None:
             w._gather_tick = w._tick
         return self.last
+
+
+class CapturedTrainSteps(object):
+    """K iterations of the reference's inner training loop (experiments/simple_train.py:257-300) in ONE HIP graph:
+
+        action_n = act_all(trainers, obs_n, out=env.action_views)      # every actor + Gumbel-softmax sample: 1 launch
+        new_obs_n, rew_n, done_n, info_n = env.step(action_n)          # fused env step: 1 launch
+        add_all(buffers, obs_n, action_n, rew_n, new_obs_n, done_n)    # every agent's replay append: 1 launch
+        obs_n = new_obs_n
+
+    Below ~10^5 envs these three launches take 20-40 us on the GPU and 200-300 us of Python + ctypes on the host; a
+    replay of the recorded launches leaves the GPU time.  Episode resets and the learners' updates stay outside (call
+    ``env.reset()`` / ``trainer.update`` between replays, as the reference does every max_episode_len / 100 steps).
+
+    A recorded launch bakes its arguments.  What moves from replay to replay lives in device memory instead: the call
+    counter that keys the actors' Philox noise (``mpe_actor_forward_multi_ctr_f32``) and every replay ring's append
+    cursor (``mpe_replay_add_multi_cur_*``); ``replay()`` writes both words from the host-side bookkeeping before it
+    launches the graph, so eager calls may be mixed with replays freely.  The actors' packed weights are refilled in
+    place by ``trainer.update``.  Call after at least one eager iteration (the rings and the packed weights must exist)
+    and with current observations (right after ``env.reset()`` or ``env.step``)."""
+
+    def __init__(self, env, trainers, K, kernel=0):
+        from .maddpg import act_all
+        from .replay_buffer import add_all
+        if not env._fused:
+            raise RuntimeError('CapturedTrainSteps needs the fused step (built-in scenario callbacks)')
+        w = env.world
+        self.env, self.trainers, self.K = env, list(trainers), int(K)
+        self.buffers = [tr.replay_buffer for tr in self.trainers]
+        if any(tr._packed is None for tr in self.trainers) or any(b._ring is None for b in self.buffers):
+            raise RuntimeError('run one eager act_all / env.step / add_all iteration before capturing')
+        if w.obs is None or w._obs_tick != w._tick:
+            raise RuntimeError('capture right after env.reset() or env.step(): the observations must be current')
+        self.ctr = torch.zeros(1, dtype=torch.int32, device=w.device)
+        for b in self.buffers:
+            b.device_cursor().zero_()
+        self._base_calls = self.trainers[0]._act_calls
+        self._base_idx = [b._next_idx for b in self.buffers]
+        self._slot0 = w._obs_slot
+        host = ([tr._act_calls for tr in self.trainers], [(b._next_idx, b._len, getattr(b, '_keep', None)) for b in self.buffers],
+                (w._tick, w._obs_tick, w._gather_tick, w.act))
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(w.device)
+        with _hip.on_device(w.device):
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                obs_n = list(w.obs_views)
+                for _ in range(self.K):
+                    action_n = act_all(self.trainers, obs_n, out=env.action_views, kernel=kernel, counter_dev=self.ctr)
+                    new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+                    add_all(self.buffers, obs_n, action_n, rew_n, new_obs_n, done_n, cursors=True)
+                    obs_n = new_obs_n
+                self.last = (new_obs_n, rew_n, done_n, info_n)
+        self._slot_after = w._obs_slot
+        self._act_after = w.act
+        self._n = w.num_envs
+        # a capture executes nothing, but the host-side bookkeeping moved: put it back
+        for tr, c in zip(self.trainers, host[0]):
+            tr._act_calls = c
+        for b, (i, l, k) in zip(self.buffers, host[1]):
+            b._next_idx, b._len, b._keep = i, l, k
+        w._tick, w._obs_tick, w._gather_tick, w.act = host[2]
+        self._set_slot(self._slot0)
+
+    def _set_slot(self, slot):
+        w = self.env.world
+        w._obs_slot = slot
+        w.obs, w.obs_views = w._obs_pair[slot], w._views_pair[slot]
+        w._buf.set(obs=w.obs)
+
+    def replay(self):
+        """Runs the K iterations; returns the last one's ``(obs_n, reward_n, done_n, info_n)``."""
+        w = self.env.world
+        if w._obs_tick != w._tick:
+            raise RuntimeError('replay right after env.reset() or env.step(): the observations must be current')
+        if w._obs_slot != self._slot0:      # the current observations sit in the other buffer: move them
+            w._obs_pair[self._slot0].copy_(w._obs_pair[w._obs_slot])
+            self._set_slot(self._slot0)
+        delta = (self.trainers[0]._act_calls - self._base_calls) & 0xFFFFFFFF
+        self.ctr.fill_(delta - (1 << 32) if delta >= (1 << 31) else delta)
+        for b, base in zip(self.buffers, self._base_idx):
+            b.device_cursor().fill_((b._next_idx - base) % b._maxsize)
+        self.graph.replay()
+        for b in self.buffers:
+            b.device_cursor().zero_()                  # eager add_all(cursors=True) calls see no offset
+        for tr in self.trainers:
+            tr._act_calls += self.K
+        for b in self.buffers:
+            b._next_idx = (b._next_idx + self.K * self._n) % b._maxsize
+            b._len = min(b._len + self.K * self._n, b._maxsize)
+        self._set_slot(self._slot_after)
+        w.act = self._act_after
+        w._tick += self.K
+        w._obs_tick = w._tick
+        if self.env.info_callback is not None:
+            w._gather_tick = w._tick
+        return self.last

@@ -56,9 +56,10 @@ def soft_sample(flat, sizes, generator=None):
 ACTOR_HIDDEN, ACTOR_MAX_OUT = 64, 16       # MPE_ACTOR_HIDDEN / MPE_ACTOR_MAX_OUT (include/mpe_hip.h)
 
 
-def pack_actor(net):
+def pack_actor(net, out=None):
     """The packed f32 weight array mpe_actor_forward_f32 reads (include/mpe_hip.h): W1t [in][64], b1 [64],
-    W2t [64][64], b2 [64], W3t [64][16], b3 [16]; or None when ``net`` is not the stock 2 x 64 model."""
+    W2t [64][64], b2 [64], W3t [64][16], b3 [16]; or None when ``net`` is not the stock 2 x 64 model.
+    ``out``: an earlier result to refill in place (its address may be recorded in a HIP graph, marl_amd/graph.py)."""
     lin = [m for m in net if isinstance(m, nn.Linear)] if isinstance(net, nn.Sequential) else []
     if (len(lin) != 3 or len(net) != 5 or lin[0].out_features != ACTOR_HIDDEN or lin[1].out_features != ACTOR_HIDDEN
             or lin[2].out_features > ACTOR_MAX_OUT or lin[0].weight.dtype != torch.float32):
@@ -67,8 +68,11 @@ def pack_actor(net):
     b3 = torch.zeros(ACTOR_MAX_OUT, device=lin[2].weight.device)
     w3[:, :lin[2].out_features] = lin[2].weight.detach().t()
     b3[:lin[2].out_features] = lin[2].bias.detach()
-    return torch.cat([lin[0].weight.detach().t().reshape(-1), lin[0].bias.detach(), lin[1].weight.detach().t().reshape(-1),
-                      lin[1].bias.detach(), w3.reshape(-1), b3]).contiguous()
+    packed = torch.cat([lin[0].weight.detach().t().reshape(-1), lin[0].bias.detach(), lin[1].weight.detach().t().reshape(-1),
+                        lin[1].bias.detach(), w3.reshape(-1), b3]).contiguous()
+    if out is not None and out.shape == packed.shape and out.device == packed.device:
+        return out.copy_(packed)
+    return packed
 
 
 def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0, kernel=0):
@@ -97,14 +101,18 @@ def actor_forward(packed, obs, sizes, u=None, seed=0, call_counter=0, env_id0=0,
 
 
 @torch.no_grad()
-def act_all(trainers, obs_n, out=None, kernel=0):
+def act_all(trainers, obs_n, out=None, kernel=0, counter_dev=None):
     """``[tr.action(obs) for tr, obs in zip(trainers, obs_n)]`` (experiments/simple_train.py:260) with every agent's
     network + Gumbel-softmax sample in ONE launch (libmpe_hip.so: mpe_actor_forward_multi_f32).  Falls back to the
     per-agent calls when some agent's observation / model is not what the fused kernel takes.
 
     ``out``: ``env.action_views`` -- the kernel then writes straight into the env's SoA action rows and ``env.step``
     of the returned list copies nothing (without it each agent's action lands in a fresh buffer that ``env.step``
-    copies row-wise: 4 x 9 us per step for simple_tag at 1 Mi envs)."""
+    copies row-wise: 4 x 9 us per step for simple_tag at 1 Mi envs).
+
+    ``counter_dev``: an int32 device tensor whose word 0 is added to the call counter that keys the Gumbel noise
+    (mpe_actor_forward_multi_ctr_f32): marl_amd.graph.CapturedTrainSteps records acting steps in a HIP graph and moves
+    that word between replays.  Needs the fused path (raises otherwise)."""
     from . import _hip
     t0, o0 = trainers[0], obs_n[0]
     fused = o0.dim() == 2 and o0.shape[1] > 1
@@ -118,6 +126,8 @@ def act_all(trainers, obs_n, out=None, kernel=0):
             tr._packed = pack_actor(tr.p)
         fused = fused and tr._packed is not None
     if not fused:
+        if counter_dev is not None:
+            raise RuntimeError('act_all(counter_dev=...) needs the fused actor kernel for every agent')
         return [tr.action(obs) for tr, obs in zip(trainers, obs_n)]
     nouts = [sum(tr.sizes_n[tr.agent_index]) for tr in trainers]
     # action rows: the caller's SoA views when they share one row stride, else fresh buffers with the observations' stride
@@ -136,8 +146,9 @@ def act_all(trainers, obs_n, out=None, kernel=0):
                       tr.sizes_n[tr.agent_index][0], (tr.sizes_n[tr.agent_index] + [0])[1], tr.seed)
         for tr, obs, act in zip(trainers, obs_n, acts)])
     with _hip.on_device(o0.device):
-        _hip.check(_hip.lib.mpe_actor_forward_multi_f32(len(trainers), jobs, B, ld, ld_act, t0._act_calls, t0.env_id0,
-                                                        kernel, _hip.stream_of(o0.device)), 'mpe_actor_forward_multi')
+        _hip.check(_hip.lib.mpe_actor_forward_multi_ctr_f32(
+            len(trainers), jobs, B, ld, ld_act, t0._act_calls, None if counter_dev is None else counter_dev.data_ptr(),
+            t0.env_id0, kernel, _hip.stream_of(o0.device)), 'mpe_actor_forward_multi')
     return acts
 
 
@@ -268,7 +279,8 @@ class MADDPGAgentTrainer(object):
         p_loss.backward()                                                 # only p's variables are stepped (:58)
         clip_by_norm_(self.p.parameters(), self.grad_norm_clipping)
         self.p_opt.step()
-        self._packed = None
+        if self._packed is not None:          # refilled in place: a captured acting step keeps reading this buffer
+            pack_actor(self.p, out=self._packed)
         self.q_opt.zero_grad(set_to_none=True)
 
         polyak_update_(self.p, self.target_p)                             # :193-194

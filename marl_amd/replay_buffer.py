@@ -26,6 +26,7 @@ class ReplayBuffer(object):
         self.check_index = True    # validate sample indices like the reference's list indexing (one host sync)
         self._ring = None          # [capacity, width], allocated by the first add()
         self._dims = None          # (obs_dim, act_dim)
+        self._cursor_dev = None    # int64[1]: moving part of the ring cursor for appends recorded in a HIP graph
 
     def __len__(self):             # :18-19
         return self._len
@@ -33,6 +34,13 @@ class ReplayBuffer(object):
     def clear(self):               # :21-23
         self._len = 0
         self._next_idx = 0
+
+    def device_cursor(self):
+        """int64 device word that ``add_all(..., cursors=True)`` adds to the append position (mpe_replay_add_multi_cur_*):
+        0 outside graph replays (marl_amd.graph.CapturedTrainSteps sets it before each replay)."""
+        if self._cursor_dev is None:
+            self._cursor_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        return self._cursor_dev
 
     def _seg(self, t, n):
         """mpe_replay_seg of a [n, d] / [n] tensor with arbitrary strides."""
@@ -120,9 +128,10 @@ class ReplayBuffer(object):
         return self.sample(-1)
 
 
-def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n):
+def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n, cursors=False):
     """``buffers[i].add(obs_n[i], action_n[i], reward_n[i], obs_tp1_n[i], done_n[i])`` for every agent (the loop of
-    experiments/simple_train.py:284-287) in ONE launch (libmpe_hip.so: mpe_replay_add_multi_*)."""
+    experiments/simple_train.py:284-287) in ONE launch (libmpe_hip.so: mpe_replay_add_multi_*).
+    ``cursors``: append at ``_next_idx + *device_cursor()`` (mpe_replay_add_multi_cur_*; for HIP-graph capture)."""
     b0 = buffers[0]
     if any(b.device != b0.device or b.dtype != b0.dtype for b in buffers):
         raise ValueError('add_all needs buffers on one device with one dtype')
@@ -136,8 +145,13 @@ def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n):
         raise ValueError('every agent must add the same number of transitions')
     jobs = (_hip.ReplayJob * len(buffers))(*[_hip.ReplayJob(b._maxsize, b._next_idx, p[1], 5, p[2], b._ring.data_ptr())
                                              for b, p in zip(buffers, prep)])
-    fn = getattr(_hip.lib, 'mpe_replay_add_multi_' + _hip.suffix(b0.dtype))
     with _hip.on_device(b0.device):
-        _hip.check(fn(len(buffers), jobs, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi')
+        if cursors:
+            cur = (C.c_void_p * len(buffers))(*[b.device_cursor().data_ptr() for b in buffers])
+            fn = getattr(_hip.lib, 'mpe_replay_add_multi_cur_' + _hip.suffix(b0.dtype))
+            _hip.check(fn(len(buffers), jobs, cur, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi_cur')
+        else:
+            fn = getattr(_hip.lib, 'mpe_replay_add_multi_' + _hip.suffix(b0.dtype))
+            _hip.check(fn(len(buffers), jobs, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi')
     for b, p in zip(buffers, prep):
         b._advance(n, p[3])

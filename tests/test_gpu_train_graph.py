@@ -1,0 +1,98 @@
+"""marl_amd.graph.CapturedTrainSteps: K iterations of act -> step -> store recorded in one HIP graph must leave exactly
+what the eager loop leaves -- replay rings, env state, observations, the trainers' and buffers' bookkeeping -- over
+several replays with resets, an eager iteration and a weight update in between."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, seed=0):
+    from marl_amd import make_env
+    from marl_amd.maddpg import MADDPGAgentTrainer
+    env = make_env('simple_tag', num_envs=B, dtype=torch.float32, seed=seed)
+    args = types.SimpleNamespace(lr=1e-2, gamma=0.95, batch_size=256, num_units=64, max_episode_len=25)
+    obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
+    torch.manual_seed(123)                                   # identical initial networks in both copies
+    trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=B * 40,
+                                   seed=seed, env_id0=env.world.env_id0) for i in range(env.n)]
+    return env, trainers
+
+
+def _iteration(env, trainers, obs_n):
+    from marl_amd.maddpg import act_all
+    from marl_amd.replay_buffer import add_all
+    action_n = act_all(trainers, obs_n, out=env.action_views)
+    new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+    add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n)
+    return new_obs_n
+
+
+def _run(B, K, graph):
+    from marl_amd.graph import CapturedTrainSteps
+    env, trainers = _setup(B)
+    obs_n = env.reset()
+    obs_n = _iteration(env, trainers, obs_n)                 # rings and packed weights exist after this
+    obs_n = env.reset()
+    cap = CapturedTrainSteps(env, trainers, K) if graph else None
+
+    def block(obs_n):
+        if cap is not None:
+            return cap.replay()[0]
+        for _ in range(K):
+            obs_n = _iteration(env, trainers, obs_n)
+        return obs_n
+
+    obs_n = block(obs_n)
+    obs_n = env.reset()
+    obs_n = block(obs_n)
+    obs_n = _iteration(env, trainers, obs_n)                 # an eager iteration between replays
+    torch.manual_seed(7)
+    for tr in trainers:                                      # a weight update: the packed actors are refilled in place
+        tr.preupdate()
+    for tr in trainers:
+        tr.update(trainers, 100)
+    obs_n = block(obs_n)                                     # K odd: this block starts from the other observation buffer
+    torch.cuda.synchronize()
+    rings = [tr.replay_buffer._ring.clone() for tr in trainers]
+    book = [(tr._act_calls, tr.replay_buffer._next_idx, len(tr.replay_buffer)) for tr in trainers]
+    return rings, book, env.world.pos.clone(), env.world.vel.clone(), [o.clone() for o in obs_n]
+
+
+@pytest.mark.parametrize('K', [4, 5])
+def test_captured_train_steps_equal_the_eager_loop(K):
+    B = 512
+    eager, captured = _run(B, K, False), _run(B, K, True)
+    assert eager[1] == captured[1]                           # call counters, ring cursors, lengths
+    assert eager[1][0][2] == (3 * K + 2) * B
+    for a, b in zip(eager[0], captured[0]):
+        assert torch.equal(a, b)                             # every stored transition, bit for bit
+    assert torch.equal(eager[2], captured[2]) and torch.equal(eager[3], captured[3])
+    for a, b in zip(eager[4], captured[4]):
+        assert torch.equal(a, b)
+
+
+def test_ring_wrap_inside_a_replay():
+    """The device cursor is added modulo the capacity: a replay that crosses the end of the ring wraps like the eager loop."""
+    from marl_amd.graph import CapturedTrainSteps
+    res = []
+    for graph in (False, True):
+        env, trainers = _setup(512)
+        for tr in trainers:
+            tr.replay_buffer._maxsize = 512 * 7               # 1 + 4 + 4 iterations of 512: wraps in the second block
+        obs_n = _iteration(env, trainers, env.reset())
+        cap = CapturedTrainSteps(env, trainers, 4) if graph else None
+        for _ in range(2):
+            if cap is not None:
+                obs_n = cap.replay()[0]
+            else:
+                for _ in range(4):
+                    obs_n = _iteration(env, trainers, obs_n)
+        torch.cuda.synchronize()
+        res.append(([tr.replay_buffer._ring.clone() for tr in trainers],
+                    [(tr.replay_buffer._next_idx, len(tr.replay_buffer)) for tr in trainers]))
+    assert res[0][1] == res[1][1] == [(512 * 2, 512 * 7)] * 4
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)

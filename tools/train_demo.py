@@ -1,7 +1,8 @@
 """The reference's training loop shape (experiments/simple_train.py:257-300) entirely on one GPU: batched env
 step -> per-agent replay rings -> MADDPG updates every 100 steps.  Prints agent-steps/s with the learner in the
 loop (run on the GPU box from the repo root):
-    python tools/train_demo.py [scenario] [num_envs] [steps]"""
+    python tools/train_demo.py [scenario] [num_envs] [steps] [eager]
+One episode (25 iterations) is one HIP-graph replay (marl_amd.graph.CapturedTrainSteps) unless `eager` is given."""
 import os
 import sys
 import time
@@ -11,6 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marl_amd import make_env  # noqa: E402
+from marl_amd.graph import CapturedTrainSteps  # noqa: E402
 from marl_amd.maddpg import MADDPGAgentTrainer, act_all  # noqa: E402
 from marl_amd.replay_buffer import add_all  # noqa: E402
 
@@ -24,28 +26,42 @@ def main():
     obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
     trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=1 << 22,
                                    seed=0, env_id0=env.world.env_id0) for i in range(env.n)]
+    eager = len(sys.argv) > 4 and sys.argv[4] == 'eager'
     obs_n = env.reset()
     t0 = None
-    for t in range(1, steps + 101):
-        if t == 101:                                    # 100 warm-up steps, incl. the first update
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+
+    def iteration(obs_n):
         action_n = act_all(trainers, obs_n, out=env.action_views)   # every agent's actor: one launch, no copies
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
         add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n)   # one launch
-        obs_n = new_obs_n
-        if t % 25 == 0:
-            obs_n = env.reset()
+        return new_obs_n
+
+    # one episode (25 iterations of act -> step -> store) is one HIP-graph replay; resets and updates stay outside
+    EP = args.max_episode_len
+    obs_n = iteration(obs_n)                            # the rings and the packed actor weights exist after this
+    obs_n = env.reset()
+    episode = None if eager else CapturedTrainSteps(env, trainers, EP)
+    for t in range(EP, steps + 100 + 1, EP):
+        if t == 100 + EP:                               # 100 warm-up steps, incl. the first update
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if episode is not None:
+            episode.replay()
+        else:
+            for _ in range(EP):
+                obs_n = iteration(obs_n)
+        obs_n = env.reset()
         for tr in trainers:
             tr.preupdate()
         for tr in trainers:
-            out = tr.update(trainers, t)
+            out = tr.update(trainers, t)                # every 100 steps (maddpg.py:161-163), i.e. every 4th episode
         if out is not None:
             print('step %5d  q_loss %.4f  p_loss %.4f  mean reward %.3f' % (t, float(out[0]), float(out[1]), float(out[3])))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print('%s: %d envs x %d steps with %d learners in the loop: %.1f ms/step, %.3e agent-steps/s'
-          % (scenario, B, steps, env.n, 1e3 * dt / steps, B * env.n * steps / dt))
+    print('%s: %d envs x %d steps with %d learners in the loop (%s): %.3f ms/step, %.3e agent-steps/s'
+          % (scenario, B, steps, env.n, 'eager' if eager else 'one graph replay per episode', 1e3 * dt / steps,
+             B * env.n * steps / dt))
 
 
 if __name__ == '__main__':
