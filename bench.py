@@ -57,6 +57,12 @@ WORKLOADS = {
     'simple_world_comm_1M_f32': ('simple_world_comm', {}, 1 << 20, torch.float32),
     'L1F4_MovingTarget_1M_f32': ('L1F4_MovingTarget', {}, 1 << 20, torch.float32),
     'S1L2F4_MovingTarget_1M_f32': ('S1L2F4_MovingTarget', {}, 1 << 20, torch.float32),
+    # fp64 (parity mode) forms of the larger worlds
+    'L1F2_3Targets_1M_f64': ('L1F2_3Targets_100observe', {}, 1 << 20, torch.float64),
+    'simple_world_comm_1M_f64': ('simple_world_comm', {}, 1 << 20, torch.float64),
+    'S1L2F4_MovingTarget_1M_f64': ('S1L2F4_MovingTarget', {}, 1 << 20, torch.float64),
+    'scaled_tag_64k_f64': ('simple_tag', dict(num_adversaries=48, num_good_agents=16, num_landmarks=32),
+                           1 << 16, torch.float64),
 }
 # the other single-GPU configurations of BASELINE.json (+ the fp64 parity mode at the headline size): (name, steps, warmup)
 OTHER_CONFIGS = (('simple_spread_64k_f64', 500, 50), ('scaled_tag_256k_f32', 100, 25), ('simple_tag_1M_f64', 250, 25))

@@ -19,7 +19,7 @@ struct DevDesc {
   int32_t kind, A, L, E, dim_c, obs_total, info_w, n_adv;
   int32_t n_good;       // agents that are not adversaries
   int32_t ncol_prefix;  // >= 0: exactly the entities [0, ncol_prefix) collide (fast pair loop); -1: irregular
-  T dt, damp1 /* 1 - damping */, cforce, k, inv_k /* f32 fast path only */;
+  T dt, damp1 /* 1 - damping */, cforce, k, inv_k /* RN(1 / k) */;
   T size[MPE_MAX_ENTITIES];
   T mass[MPE_MAX_AGENTS];
   T accel[MPE_MAX_AGENTS];
@@ -189,6 +189,113 @@ __device__ __forceinline__ void pair_force(T dx, T dy, T dmin, const DevDesc<T> 
   fy = (d.cforce * dy) / dist * pen;
 }
 
+// ---- f64 pair force without the library calls -------------------------------------------------------------------
+// The generic form above costs ~270 instructions per pair in f64, half of them ocml's log1p (~140; exp ~50, the
+// scaled sqrt 17, three IEEE divides 11 each): simple_tag f64 was 3 200 instructions per wavefront and ran at 0.51
+// VALU utilisation beside the HBM stream, the 10-target hierarchy world (60 pairs) was compute-bound outright.  The
+// pieces below use what this call site knows -- exp of a non-positive number, log1p of a number in [0, 1], a
+// denominator that is a square root just computed, a divisor that is a launch constant -- and come to ~95.
+// Accuracy (host emulation over 2e7 samples with 2^-23 seeds, tools/f64_math_check.c; GPU: tests/test_gpu_parity.py):
+// the square root and both quotient forms are correctly rounded (equal to IEEE sqrt / divide on every sample),
+// exp <= 0.88 ulp, log1p <= 0.83 ulp; numpy's own libm is within 1 ulp on the same two, so the distance to the
+// reference stays where it was (~1e-15 after 25 steps; bar 1e-9).
+#ifndef MPE_F64_RCP_NR
+#define MPE_F64_RCP_NR 2  // Newton steps on v_rcp_f64 (1 would do if the seed is good to 2^-27; 2 is safe from 2^-14)
+#endif
+__device__ __forceinline__ double rcp_nr(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+#pragma unroll
+  for (int i = 0; i < MPE_F64_RCP_NR; ++i) {
+    const double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+  }
+  return y;
+}
+// exp(-a) for a >= 0.  n = rint(-a log2 e), r = -a - n ln2 (two-piece ln2, |r| <= 0.347), Taylor to r^13
+// (truncation 4e-18), ldexp.  a is clamped at 800 (exp(-745.2) already rounds to 0; the clamp keeps n and r finite for
+// a = inf and turns a NaN into 0: the caller's NaN reaches the force through the division by dist).
+__device__ __forceinline__ double exp_neg_f64(double a) {
+  const double y = -fmin(a, 800.0);
+  const double n = rint(y * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, y);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+// log1p(t) for t in [0, 1] (fdlibm's s_log1p.c scheme: u = 1 + t with its rounding error c carried as c / u, u = 2^k m
+// with m in [sqrt(1/2), sqrt 2), f = m - 1, s = f / (2 + f), log m = f - f^2/2 + s (f^2/2 + R(s^2))).  Both quotients go
+// through refined reciprocals: s is multiplied by an O(f^2) term, and c / u is the whole result when t < 2^-53.
+__device__ __forceinline__ double log1p_unit_f64(double t) {
+  const double u = 1.0 + t;
+  const double c = (t - (u - 1.0)) * rcp_nr(u);
+  const bool up = u >= 1.4142135623730951;
+  const double kd = up ? 1.0 : 0.0;
+  const double f = u * (up ? 0.5 : 1.0) - 1.0;
+  const double hfsq = 0.5 * f * f;
+  const double s = f * rcp_nr(2.0 + f), z = s * s;
+  double R = fma(z, 1.479819860511658591e-01, 1.531383769920937332e-01);
+  R = fma(z, R, 1.818357216161805012e-01);
+  R = fma(z, R, 2.222219843214978396e-01);
+  R = fma(z, R, 2.857142874366239149e-01);
+  R = fma(z, R, 3.999999999940941908e-01);
+  R = fma(z, R, 6.666666666666735130e-01);
+  R = R * z;
+  const double lo = fma(kd, 1.90821492927058770002e-10, c);
+  return fma(kd, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, lo)) - f));
+}
+// sqrt(x) and 1 / sqrt(x) from one v_rsq_f64: the compiler's own sqrt expansion (one Goldschmidt step, two residual
+// corrections) without its input scaling, which only matters below 2^-767; x = 0 gives NaN, which is what the caller's
+// 0 / 0 gives the reference.  rinv is good to ~2^-50: a seed for quot().
+__device__ __forceinline__ void sqrt_rcp_f64(double x, double &root, double &rinv) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  double g = x * y0, h = 0.5 * y0;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double e = fma(-g, g, x);
+  g = fma(e, h, g);
+  e = fma(-g, g, x);
+  root = fma(e, h, g);
+  rinv = h + h;
+}
+// n / b given y ~ 1 / b: one residual step (Markstein).  With y = RN(1/b) the result is the correctly rounded quotient
+// (Brisebarre, Muller, Raina 2004: division by a constant); with a ~2^-50 seed it still was on every sample tried.
+__device__ __forceinline__ double quot(double n, double b, double y) {
+  const double q = n * y;
+  return fma(fma(-q, b, n), y, q);
+}
+template <>
+__device__ __forceinline__ void pair_force<double>(double dx, double dy, double dmin, const DevDesc<double> &d,
+                                                   double &fx, double &fy) {
+#ifdef MPE_F64_OCML
+  const double dist = sqrt(dx * dx + dy * dy);
+  const double x = -(dist - dmin) / d.k;
+  const double pen = ((x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)))) * d.k;
+  fx = (d.cforce * dx) / dist * pen;
+  fy = (d.cforce * dy) / dist * pen;
+#else
+  double dist, rdist;
+  sqrt_rcp_f64(dx * dx + dy * dy, dist, rdist);
+  const double x = quot(-(dist - dmin), d.k, d.inv_k);
+  const double pen = ((x > 0.0 ? x : 0.0) + log1p_unit_f64(exp_neg_f64(fabs(x)))) * d.k;
+  fx = quot(d.cforce * dx, dist, rdist) * pen;
+  fy = quot(d.cforce * dy, dist, rdist) * pen;
+#endif
+}
+
 // f32 (throughput mode, stated tolerance 1e-4 relative): hardware rsq / exp2 / log2 (each ~1 ulp)
 // instead of the ~230-instruction correctly-rounded sequence; one reciprocal shared by both
 // components.  log(1+e) for e < 2^-24 returns 0 instead of e: an absolute softplus error <= 6e-8,
@@ -212,21 +319,66 @@ template <typename T> __device__ __forceinline__ T t_div(T a, T b) { return a / 
 // f32: a * rcp(b) (v_rcp_f32, ~1 ulp) instead of the IEEE divide sequence
 template <> __device__ __forceinline__ float t_div<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
+// (dx, dy) / np.linalg.norm((dx, dy)) (core.py:185-189).  f64: root and quotients from one v_rsq_f64 (sqrt_rcp_f64 / quot:
+// the same doubles as the IEEE sqrt and divides, ~20 instructions instead of ~40; a zero vector gives NaN both ways).
+template <typename T>
+__device__ __forceinline__ void unit_vec(T dx, T dy, T &ux, T &uy) {
+  const T n = t_norm2<T>(dx, dy);
+  ux = t_div<T>(dx, n);
+  uy = t_div<T>(dy, n);
+}
+template <>
+__device__ __forceinline__ void unit_vec<double>(double dx, double dy, double &ux, double &uy) {
+  double n, rn;
+  sqrt_rcp_f64(fma(dy, dy, dx * dx), n, rn);
+  ux = quot(dx, n, rn);
+  uy = quot(dy, n, rn);
+}
+
+// F / mass (core.py:216).  f64: every entity of every scenario file has mass 1.0 (core.py:47,51-53), and the mass is a
+// launch constant: a scalar branch skips the 11-instruction IEEE divide then (F / 1.0 == F).
+template <typename T> __device__ __forceinline__ T over_mass(T F, T mass) { return t_div<T>(F, mass); }
+template <> __device__ __forceinline__ double over_mass<double>(double F, double mass) {
+  if (mass == 1.0) return F;
+  return F / mass;
+}
+
+// The max_speed clamp of integrate_state (core.py:217-221): speed = sqrt(vx^2 + vy^2); if speed > max_speed:
+// v = v / speed * max_speed (divide first, then multiply).  Branch-free (selects) in f32.
+template <typename T>
+__device__ __forceinline__ void speed_clamp(T &vx, T &vy, T max_speed) {
+  const T sp = t_sqrt<T>(vx * vx + vy * vy);
+  const T cx = t_div<T>(vx, sp) * max_speed, cy = t_div<T>(vy, sp) * max_speed;
+  const bool clamp = sp > max_speed;
+  vx = clamp ? cx : vx;
+  vy = clamp ? cy : vy;
+}
+// f64: the square root and the two divides (~40 instructions) only run for lanes that can be over the limit.  sqrt is
+// monotonic, so v2 <= max^2 (1 - 2^-50) implies sqrt(v2) <= max: those lanes (nearly all: a wavefront whose 64 envs all
+// stay below skips the block) decide on the squares; the others evaluate the reference's expression, with the
+// correctly rounded root and quotients of sqrt_rcp_f64 / quot.  NaN speeds are left alone both ways.
+template <>
+__device__ __forceinline__ void speed_clamp<double>(double &vx, double &vy, double max_speed) {
+  const double v2 = vx * vx + vy * vy;
+  if (v2 > max_speed * max_speed * (1.0 - 0x1p-50)) {
+    double sp, rsp;
+    sqrt_rcp_f64(v2, sp, rsp);
+    const double cx = quot(vx, sp, rsp) * max_speed, cy = quot(vy, sp, rsp) * max_speed;
+    const bool clamp = sp > max_speed;
+    vx = clamp ? cx : vx;
+    vy = clamp ? cy : vy;
+  }
+}
+
 // integrate_state (core.py:214-221) for one movable entity; returns new velocity.
 template <typename T>
 __device__ __forceinline__ void integrate_vel(T &vx, T &vy, T Fx, T Fy, T mass, T damp1, T dt,
                                               T max_speed) {
   vx = vx * damp1;
   vy = vy * damp1;
-  vx = vx + t_div<T>(Fx, mass) * dt;
-  vy = vy + t_div<T>(Fy, mass) * dt;
-  if (max_speed >= T(0)) {
-    const T sp = t_sqrt<T>(vx * vx + vy * vy);
-    if (sp > max_speed) {  // divide first, then multiply (core.py:220-221)
-      vx = t_div<T>(vx, sp) * max_speed;
-      vy = t_div<T>(vy, sp) * max_speed;
-    }
-  }
+  vx = vx + over_mass<T>(Fx, mass) * dt;
+  vy = vy + over_mass<T>(Fy, mass) * dt;
+  if (max_speed >= T(0)) speed_clamp<T>(vx, vy, max_speed);
 }
 
 // Same arithmetic, branch-free (selects), for the straight-line register kernel.  HAS_MAX is the
@@ -236,15 +388,9 @@ __device__ __forceinline__ void integrate_vel_sel(T &vx, T &vy, T Fx, T Fy, T ma
                                                   T max_speed) {
   vx = vx * damp1;
   vy = vy * damp1;
-  vx = vx + t_div<T>(Fx, mass) * dt;
-  vy = vy + t_div<T>(Fy, mass) * dt;
-  if (HAS_MAX) {
-    const T sp = t_sqrt<T>(vx * vx + vy * vy);
-    const T cx = t_div<T>(vx, sp) * max_speed, cy = t_div<T>(vy, sp) * max_speed;
-    const bool clamp = sp > max_speed;
-    vx = clamp ? cx : vx;
-    vy = clamp ? cy : vy;
-  }
+  vx = vx + over_mass<T>(Fx, mass) * dt;
+  vy = vy + over_mass<T>(Fy, mass) * dt;
+  if (HAS_MAX) speed_clamp<T>(vx, vy, max_speed);
 }
 
 // apply_leader_force (core.py:153-194) for agent a of the env in column `col`: every leader whose
@@ -289,9 +435,7 @@ __device__ __forceinline__ void leader_force(const KParams<T> &p, int a, int64_t
     else if (cmd == 5 || cmd == 6) {
       T dx = pos_of(l, 0) - pos_of(a, 0), dy = pos_of(l, 1) - pos_of(a, 1);
       if (cmd == 6) { dx = pos_of(a, 0) - pos_of(l, 0); dy = pos_of(a, 1) - pos_of(l, 1); }
-      const T n = t_norm2<T>(dx, dy);
-      fx = t_div<T>(dx, n);
-      fy = t_div<T>(dy, n);
+      unit_vec<T>(dx, dy, fx, fy);
     }
     Fx = Fx + fx;
     Fy = Fy + fy;

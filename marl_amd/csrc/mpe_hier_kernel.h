@@ -90,8 +90,8 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
         }
         const int k = cmd[l - NF];
         const T dx = px[l] - px[a], dy = py[l] - py[a];
-        const T n = t_norm2<T>(dx, dy);
-        const T ux = t_div<T>(dx, n), uy = t_div<T>(dy, n);  // cmd 6 is exactly the negation
+        T ux, uy;  // cmd 6 is exactly the negation
+        unit_vec<T>(dx, dy, ux, uy);
         T fx = k == 1 ? -T(1) : (k == 2 ? T(1) : T(0));
         T fy = k == 3 ? -T(1) : (k == 4 ? T(1) : T(0));
         fx = k == 5 ? ux : (k == 6 ? -ux : fx);
