@@ -410,6 +410,49 @@ def test_episode_stats_rows_and_reduce(mk, force_tile):
     assert out[2 * A + 1].item() == 6 * B and out[A:2 * A].sum().item() > 0
 
 
+def test_f64_contact_force_relative_accuracy(force_tile):
+    """The f64 pair force uses the library's own exp / log1p / sqrt / quotient forms (mpe_device.h: exp_neg_f64,
+    log1p_unit_f64, sqrt_rcp_f64, quot) instead of ocml's.  Their error is relative, so it is checked as such over the
+    whole range of get_collision_force (core.py:233-249): separations from 1e-7 (deep overlap, x = +150) through the
+    contact threshold to the softplus tail, where the force is 1e-300 and below (KAT-4 of SURVEY 8c: the tail is not an
+    exact zero) and finally underflows.  Bar: 8 ulp of the oracle's float64 value, exact zeros where it has them."""
+    spec = O.simple_tag_spec()
+    B = 60000
+    rng = np.random.RandomState(11)
+    sep = np.concatenate([10.0 ** rng.uniform(-7, -1, B // 4),        # overlapping
+                          0.15 + rng.uniform(-0.05, 0.05, B // 4),      # around dist_min = 0.075 + 0.075
+                          0.15 + rng.uniform(0.0, 0.8, B // 4),         # the tail, down to the smallest normals
+                          0.15 + rng.uniform(0.7, 3.0, B - 3 * (B // 4))])  # subnormal results, then exact zeros
+    ang = rng.uniform(0, 2 * np.pi, B)
+    pos = np.zeros((6, 2, B))
+    pos[0] = rng.uniform(-1, 1, (2, B))
+    pos[1, 0] = pos[0, 0] + sep * np.cos(ang)
+    pos[1, 1] = pos[0, 1] + sep * np.sin(ang)
+    for e in range(2, 6):                                               # everybody else: exact-zero forces
+        pos[e, 0] = 20.0 * e
+    vel = np.zeros((4, 2, B))
+    act = np.zeros((4, 5, B))
+    sim = HipSim(spec, B, torch.float64)
+    sim.set_state(pos, vel)
+    sim.world_step(dev(act, torch.float64))
+    _, want = O.BatchedOracle(spec).world_step(pos, vel, act)
+    got = sim.host()[1]
+    w, g = want[0], got[0]                                              # agent 0 is the one pushed (one-sided)
+    assert np.isfinite(w).all() and np.isfinite(g).all()
+    # subnormal results: the penalty is rounded to a multiple of 4.9e-324 before it is scaled by contact_force * d / dist
+    # (up to 100) and dt, so one subnormal step of difference in exp() shows as up to ~10 steps here
+    tiny = np.abs(w) < 2.3e-308
+    sub = float(np.max(np.abs(g - w)[tiny])) / 4.95e-324
+    print('f64 pair force, subnormal results: max difference %.0f subnormal steps' % sub)
+    assert sub <= 64
+    rel = np.abs(g - w)[~tiny] / np.abs(w)[~tiny]
+    print('f64 pair force: max relative error %.2e (%.1f ulp), %d exact zeros, %d subnormal'
+          % (rel.max(), rel.max() / 2.2e-16, int((w == 0).sum()), int((tiny & (w != 0)).sum())))
+    assert rel.max() <= 8 * 2.2e-16
+    assert (w == 0).sum() > 1000 and (np.abs(w[~tiny]) < 1e-290).sum() > 100   # the sweep reached both ends
+    assert np.array_equal(got[1:], want[1:])                            # nobody else moves
+
+
 def test_coincident_entities_give_nan_like_the_reference():
     """dist == 0 -> delta/dist = NaN in the reference (core.py:246); parity means not 'fixing' it."""
     spec = O.simple_tag_spec()
