@@ -496,7 +496,11 @@ __device__ __forceinline__ bool touching_d2<double>(double d2, double dmin) {
   const double m2 = dmin * dmin;
   const double lo = m2 * (1.0 - 0x1p-50), hi = m2 * (1.0 + 0x1p-50);
   bool r = d2 < lo;
-  if (d2 >= lo && d2 <= hi) r = sqrt(d2) < dmin;
+  if (d2 >= lo && d2 <= hi) {  // (written out: the compiler speculates a bare sqrt() call, 17 instructions, out of the branch)
+    double root, rinv;
+    sqrt_rcp_f64(d2, root, rinv);
+    r = root < dmin;
+  }
   return r;
 }
 template <typename T>

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         tdx[l] = px[A + l] - px[i];
         tdy[l] = py[A + l] - py[i];
         td2[l] = tdx[l] * tdx[l] + tdy[l] * tdy[l];
-        n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;  // (the sqrt-free f64 test costs registers here: +2 %)
+#ifdef MPE_HIER_SQRT_CONTACT
+        n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;
+#else
+        n += touching_d2<T>(td2[l], d.size[A + l] + d.size[i]) ? 1 : 0;
+#endif
       }
       hits[i] = n;
       if (!want_obs) continue;
