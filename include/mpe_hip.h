@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 7
+#define MPE_ABI_VERSION 8
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -296,6 +296,28 @@ int mpe_scripted_action_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld
                             double cap, const void *pos, void *act_out, void *point_out, void *stream);
 int mpe_scripted_action_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int agent, int mode, int target,
                             double cap, const void *pos, void *act_out, void *point_out, void *stream);
+
+/*
+ * The two non-default decodes of MultiAgentEnv._set_action (multiagent/environment.py:176-187), applied to the SoA
+ * action rows `act` ([mpe_act_total][ld], same layout as mpe_buffers.act) before a step call, which always runs the
+ * default decode (:188-190).  One launch for all agents; agents that are not movable have no physical entries and
+ * are skipped (:174).
+ *   mpe_action_from_index  env.discrete_action_input (:176-182): idx is int32 [n_agents][ld_idx], one integer per agent
+ *                          and env; 1 / 2 -> u[0] = -1 / +1, 3 / 4 -> u[1] = -1 / +1, any other value -> no force.  The
+ *                          agent's 5 rows are written so that the default decode reproduces that u (as a one-hot INDEX 1
+ *                          would mean +1: the rows are not one_hot(idx)).  A world with a speaking agent is refused
+ *                          (MPE_ERR_UNSUPPORTED): the reference's integer decode of a comm action fails its own
+ *                          `assert len(action) == 0` (:200-208).
+ *   mpe_action_force_discrete  env.force_discrete_action, i.e. world.discrete_action (:33,184-187): the physical 5
+ *                          entries of every movable agent become one_hot(np.argmax(.)) in place (first maximum; a
+ *                          NaN wins); comm entries are left as they are.
+ */
+int mpe_action_from_index_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int64_t ld_idx,
+                              const int32_t *idx, void *act, void *stream);
+int mpe_action_from_index_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int64_t ld_idx,
+                              const int32_t *idx, void *act, void *stream);
+int mpe_action_force_discrete_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, void *act, void *stream);
+int mpe_action_force_discrete_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, void *act, void *stream);
 
 /*
  * Replay buffer of the learner (maddpg/maddpg/trainer/replay_buffer.py; one per agent, maddpg.py:147): a ring

@@ -26,7 +26,7 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 7
+ABI_VERSION = 8
 FLAG_FORCE_TILE = 1
 FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
 FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
@@ -137,6 +137,10 @@ def _load():
         f.restype, f.argtypes = ci, [dp, i64, i64, u64, u32, u64, bp, vp, vp]
         f = getattr(L, 'mpe_scripted_action_' + suf)  # desc, B, ld, agent, mode, target, cap, pos, act, point, stream
         f.restype, f.argtypes = ci, [dp, i64, i64, ci, ci, ci, C.c_double, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_action_from_index_' + suf)  # desc, B, ld, ld_idx, idx, act, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, i64, vp, vp, vp]
+        f = getattr(L, 'mpe_action_force_discrete_' + suf)  # desc, B, ld, act, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp]
         f = getattr(L, 'mpe_replay_add_' + suf)       # capacity, next_idx, n, width, nseg, segs, ring, stream
         f.restype, f.argtypes = ci, [i64, i64, i64, ci, ci, C.POINTER(ReplaySeg), vp, vp]
         f = getattr(L, 'mpe_replay_add_multi_' + suf)  # n_jobs, jobs, n, stream

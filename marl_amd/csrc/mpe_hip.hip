@@ -695,6 +695,97 @@ static int scripted_action_impl(const mpe_scenario_desc *h, int64_t B, int64_t l
 }
 
 // ------------------------------------------------------------------------------------------------
+// The two non-default decodes of MultiAgentEnv._set_action (environment.py:176-187), as a pass over the SoA action
+// rows in front of the step kernels (which always run the default decode, :188-190):
+//   discrete_action_input (:176-182): the action is an integer; 1 / 2 -> u[0] = -1 / +1, 3 / 4 -> u[1] = -1 / +1,
+//     anything else nothing.  Written as the 5-vector whose default decode gives the same u: note the SIGN -- as a
+//     one-hot vector index 1 means u[0] = +1 (a[1] - a[2]), as an integer it means -1 -- so the integer k sets entry
+//     {0, 2, 1, 4, 3}[k].
+//   force_discrete_action (:184-187): d = np.argmax(a[0:5]) (first maximum, a NaN wins), a[0:5] = one_hot(d), in place;
+//     comm entries untouched.
+// One launch for every movable agent: blockIdx.y = agent.
+// ------------------------------------------------------------------------------------------------
+struct ActRows {
+  int32_t row0[MPE_MAX_AGENTS];
+  uint32_t movable[MPE_MAX_AGENTS / 32];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void action_from_index_kernel(int64_t B, int64_t ld, int64_t ld_idx, ActRows m,
+                                                                const int32_t *idx, T *act) {
+  const int a = blockIdx.y;
+  if (!mpe::bit(m.movable, a)) return;
+  const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (env >= B) return;
+  const int k = __builtin_nontemporal_load(idx + (int64_t)a * ld_idx + env);
+  const int slot = k == 1 ? 2 : (k == 2 ? 1 : (k == 3 ? 4 : (k == 4 ? 3 : 0)));
+  T *o = act + (int64_t)m.row0[a] * ld + env;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) o[(int64_t)j * ld] = (j == slot && j != 0) ? T(1) : T(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void action_force_discrete_kernel(int64_t B, int64_t ld, ActRows m, T *act) {
+  const int a = blockIdx.y;
+  if (!mpe::bit(m.movable, a)) return;
+  const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (env >= B) return;
+  T *o = act + (int64_t)m.row0[a] * ld + env;
+  T best = o[0];
+  int d = 0;
+#pragma unroll
+  for (int j = 1; j < 5; ++j) {
+    const T v = o[(int64_t)j * ld];
+    if (v > best || (v != v && best == best)) {  // np.argmax: first maximum, the first NaN wins
+      best = v;
+      d = j;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) o[(int64_t)j * ld] = j == d ? T(1) : T(0);
+}
+
+static void act_rows_of(const mpe_scenario_desc *h, ActRows &m) {
+  memset(&m, 0, sizeof(m));
+  for (int i = 0; i < h->n_agents; ++i) {
+    m.row0[i] = mpe_act_row0(h, i);
+    if (h->movable[i]) m.movable[i >> 5] |= 1u << (i & 31);
+  }
+}
+
+template <typename T>
+static int action_from_index_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, int64_t ld_idx, const int32_t *idx,
+                                  void *act, void *stream) {
+  int rc = check_common<T>(h, B, ld);
+  if (rc) return rc;
+  if (!idx || !act) return MPE_ERR_NULL;
+  if (ld_idx < B) return MPE_ERR_BATCH;
+  if (misaligned<int32_t>(idx) || misaligned<T>(act)) return MPE_ERR_ALIGN;
+  // the reference's integer decode of a speaking agent trips its own `assert len(action) == 0` (environment.py:200-208:
+  // the comm branch never consumes its entry), and a MultiDiscrete action cannot be an integer at all
+  for (int i = 0; i < h->n_agents; ++i)
+    if (!h->silent[i]) return MPE_ERR_UNSUPPORTED;
+  ActRows m;
+  act_rows_of(h, m);
+  const dim3 grid((unsigned)((B + 255) / 256), (unsigned)h->n_agents), block(256);
+  hipLaunchKernelGGL(action_from_index_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld, ld_idx, m, idx, (T *)act);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int action_force_discrete_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, void *act, void *stream) {
+  int rc = check_common<T>(h, B, ld);
+  if (rc) return rc;
+  if (!act) return MPE_ERR_NULL;
+  if (misaligned<T>(act)) return MPE_ERR_ALIGN;
+  ActRows m;
+  act_rows_of(h, m);
+  const dim3 grid((unsigned)((B + 255) / 256), (unsigned)h->n_agents), block(256);
+  hipLaunchKernelGGL(action_force_discrete_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld, m, (T *)act);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // replay buffer (maddpg/maddpg/trainer/replay_buffer.py): ring append with an SoA -> record transpose, row gather
 // ------------------------------------------------------------------------------------------------
 struct ReplaySegs {
@@ -1236,6 +1327,14 @@ extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, 
                                            int mode, int target, double cap, const void *pos, void *act_out,   \
                                            void *point_out, void *stream) {                                    \
     return scripted_action_impl<T>(d, B, ld, agent, mode, target, cap, pos, act_out, point_out, stream);       \
+  }                                                                                                            \
+  extern "C" int mpe_action_from_index_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, int64_t ld_idx, \
+                                             const int32_t *idx, void *act, void *stream) {                    \
+    return action_from_index_impl<T>(d, B, ld, ld_idx, idx, act, stream);                                      \
+  }                                                                                                            \
+  extern "C" int mpe_action_force_discrete_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, void *act,  \
+                                                 void *stream) {                                               \
+    return action_force_discrete_impl<T>(d, B, ld, act, stream);                                               \
   }                                                                                                            \
   extern "C" int mpe_replay_add_##SUF(int64_t capacity, int64_t next_idx, int64_t n, int width, int nseg,      \
                                       const mpe_replay_seg *segs, void *ring, void *stream) {                  \

@@ -21,7 +21,7 @@ run as given, agent by agent, exactly like environment.py:105-110.
 import numpy as np
 import torch
 
-from . import spaces
+from . import _hip, spaces
 from .scenario import HipScenario
 
 
@@ -47,8 +47,7 @@ class MultiAgentEnv(object):
         self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
         self.time = 0
         self.obs_r = observation_radius
-        if self.force_discrete_action:
-            raise NotImplementedError('force_discrete_action is outside the HIP hot path (SURVEY 8a a1)')
+        self._idx = None          # int32 [n, ld]: the integer actions of discrete_action_input
 
         # fused path: every callback is a built-in scenario's own method
         owners = {getattr(cb, '__self__', None) for cb in (reset_callback, reward_callback, observation_callback)}
@@ -81,8 +80,47 @@ class MultiAgentEnv(object):
         self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=world.device)
         self._empty_info = [{} for _ in range(self.n)]
 
-    # -- environment.py:157-208: the decode itself runs inside the kernel ------------------------------
+    # -- environment.py:157-208: the default decode (:188-190) runs inside the step kernels; the two other decodes
+    # rewrite the action rows in front of them (mpe_action_from_index_*, mpe_action_force_discrete_*) -----------
     def _set_actions(self, action_n):
+        if self.discrete_action_input:               # environment.py:176-182: one integer per agent
+            return self._set_index_actions(action_n)
+        self._copy_actions(action_n)
+        if self.force_discrete_action:               # environment.py:184-187: argmax -> one-hot, in place like the reference
+            w = self.world
+            fn = getattr(_hip.lib, 'mpe_action_force_discrete_' + _hip.suffix(w.dtype))
+            with _hip.on_device(w.device):
+                _hip.check(fn(w.descriptor(), w.num_envs, w.ld, w.act.data_ptr(), _hip.stream_of(w.device)),
+                           'mpe_action_force_discrete')
+
+    def _set_index_actions(self, action_n):
+        w = self.world
+        if any(not a.silent for a in self.agents):
+            # environment.py:200-208: the integer decode of a comm action never consumes its entry
+            raise AssertionError('discrete_action_input with a speaking agent: the reference fails its own '
+                                 '`assert len(action) == 0` (environment.py:208)')
+        if self._idx is None:
+            self._idx = torch.zeros(self.n, w.ld, dtype=torch.int32, device=w.device)
+        idx = self._idx[:, :self.num_envs]
+        if torch.is_tensor(action_n) and action_n.dim() == 2:
+            if tuple(action_n.shape) == (self.num_envs, self.n) and self.num_envs != self.n:
+                action_n = action_n.t()
+            if tuple(action_n.shape) != (self.n, self.num_envs):
+                raise ValueError('integer actions must be [n, num_envs] (or [num_envs, n])')
+            idx.copy_(action_n)
+        else:
+            if len(action_n) != self.n:
+                raise ValueError('need one action per agent')
+            for i, a in enumerate(action_n):
+                idx[i].copy_(torch.as_tensor(a, device=w.device).reshape(-1).expand(self.num_envs))
+        if w.act.data_ptr() != self._own_act.data_ptr():
+            w.act = self._own_act
+        fn = getattr(_hip.lib, 'mpe_action_from_index_' + _hip.suffix(w.dtype))
+        with _hip.on_device(w.device):
+            _hip.check(fn(w.descriptor(), w.num_envs, w.ld, w.ld, self._idx.data_ptr(), w.act.data_ptr(),
+                          _hip.stream_of(w.device)), 'mpe_action_from_index')
+
+    def _copy_actions(self, action_n):
         act = self.world.act
         soa = (torch.is_tensor(action_n) and action_n.dim() == act.dim() and tuple(action_n.shape) == tuple(act.shape)
                and action_n.dtype == act.dtype and action_n.device == act.device)

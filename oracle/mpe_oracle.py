@@ -364,6 +364,8 @@ class SerialEnv:
         self.n = spec.n_agents
         self.goal = 0        # index of the goal landmark (agent.goal_a), GOAL_KINDS only
         self.goals = [0] * spec.n_agents   # agent.goal_b landmark index, COMM_KINDS only
+        self.discrete_action_input = False   # environment.py:31: the action is an integer
+        self.force_discrete_action = False   # environment.py:33: argmax -> one-hot before the decode
 
     # -- state helpers ----------------------------------------------------------------
     def set_state(self, pos, vel):
@@ -402,7 +404,22 @@ class SerialEnv:
     def _decode_action(self, agent, action):
         u = np.zeros(2)
         c0 = 0
+        if self.discrete_action_input:    # environment.py:176-182; a speaking agent fails the assert at :208
+            assert agent.silent, 'environment.py:208: assert len(action) == 0'
+            if agent.movable:
+                if action == 1: u[0] = -1.0
+                if action == 2: u[0] = +1.0
+                if action == 3: u[1] = -1.0
+                if action == 4: u[1] = +1.0
+                u *= 5.0 if agent.accel is None else agent.accel
+            agent.u = u
+            agent.c_act = np.zeros(self.spec.dim_c)
+            return
         if agent.movable:                 # environment.py:174-197: only a movable agent has the physical part
+            if self.force_discrete_action:    # environment.py:184-187: in place, on the caller's array
+                d = np.argmax(action[0:5])
+                action[0:5] = 0.0
+                action[d] = 1.0
             u[0] += action[1] - action[2]
             u[1] += action[3] - action[4]
             u *= 5.0 if agent.accel is None else agent.accel
@@ -904,9 +921,32 @@ def _norm2_blas(d0, d1):
 class BatchedOracle:
     """pos[E,2,B], vel[A,2,B]; act[A,5,B]; noise[A,2,B] standard normals (or None)."""
 
-    def __init__(self, spec: ScenarioSpec, dtype=np.float64):
+    def __init__(self, spec: ScenarioSpec, dtype=np.float64, discrete_action_input=False, force_discrete_action=False):
         self.spec = spec
         self.dt = np.dtype(dtype).type
+        # environment.py:31,33.  With discrete_action_input the physical rows of an agent hold its integer action
+        # (row 0 is read); with force_discrete_action they are replaced by one_hot(argmax) before the decode.
+        self.discrete_action_input = discrete_action_input
+        self.force_discrete_action = force_discrete_action
+        if discrete_action_input:
+            assert all(spec.silent), 'environment.py:208: assert len(action) == 0'
+
+    def physical_action(self, a):
+        """The 5 physical rows a[5,B] of one movable agent -> the 5 rows the default decode (environment.py:188-190)
+        reads: unchanged, or environment.py:176-182 / :184-187 first."""
+        T = self.dt
+        if self.discrete_action_input:
+            k = a[0]
+            z = np.zeros_like(a)
+            z[2] = np.where(k == 1, T(1), T(0))     # u[0] = -1  ==  a[1] - a[2] with a[2] = 1
+            z[1] = np.where(k == 2, T(1), T(0))
+            z[4] = np.where(k == 3, T(1), T(0))
+            z[3] = np.where(k == 4, T(1), T(0))
+            return z
+        if self.force_discrete_action:
+            d = np.argmax(a, axis=0)                # first maximum; NaN counts as the maximum, like the reference's call
+            return (np.arange(5)[:, None] == d[None, :]).astype(T)
+        return a
 
     def _leader_force(self, pos, act, force):
         """core.py:153-194, vectorised; returns lforce [A,2,B] (agent.leader_force after the step)."""
@@ -961,7 +1001,7 @@ class BatchedOracle:
                 if not s.movable[i]:          # no physical part in its action (environment.py:174)
                     continue
                 sens = T(5.0 if s.accel[i] is None else s.accel[i])
-                a = act[offs[i]:offs[i] + 5]
+                a = self.physical_action(act[offs[i]:offs[i] + 5])
                 u = np.stack([(a[1] - a[2]) * sens, (a[3] - a[4]) * sens])
                 if s.movable[i]:
                     if s.u_noise[i]:

@@ -260,12 +260,25 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
                 logits = arng.randn(A, 5)
                 e = np.exp(logits - logits.max(axis=1, keepdims=True))
                 act = e / e.sum(axis=1, keepdims=True)
+            elif actions == 'index':
+                # env.discrete_action_input (environment.py:176-182): one integer per agent; 5 and 7 are outside
+                # Discrete(5) and decode to no force at all
+                act = arng.randint(0, 8, size=(A, 1)).astype(np.float64) * np.ones((1, 5))
+            elif actions == 'force':
+                # env.force_discrete_action (environment.py:184-187): values on a coarse grid, so that ties occur and
+                # np.argmax's first-maximum rule matters
+                act = arng.randint(0, 4, size=(A, 5)) / 4.0
             else:
                 act = np.zeros((A, 5))
             s_t = 30_000 + 1000 * seed + t
             np.random.seed(s_t)
             noise = np.random.RandomState(s_t).randn(A, 2)
-            obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in range(A)])
+            if actions == 'index':
+                env.discrete_action_input = True
+                obs_n, rew_n, done_n, info_n = env.step([int(act[i, 0]) for i in range(A)])
+            else:
+                env.force_discrete_action = actions == 'force'
+                obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in range(A)])
             assert not any(done_n)
             pos, vel = _state(world)
             ep['act'].append(act)
@@ -482,6 +495,7 @@ def main():
         save('m_' + name + '_dense', **rollout_hier(name, range(24), 25, init=dense_init))
         save('m_' + name + '_crowd', **rollout_hier(name, range(16), 6, init=crowd_init))
     hier_rest()
+    discrete_cases()
     kat_cases()
 
 
@@ -494,6 +508,15 @@ HIER_REST = (('L1F2_10Targets_wide', 8, 25), ('S1L1F1_10Targets_wide', 8, 25),
              ('S1L2F2_3Targets_095observe', 4, 5), ('S1L2F2_3Targets_105observe', 4, 5))
 
 
+def discrete_cases():
+    """The two non-default decodes of MultiAgentEnv._set_action.  'act' holds what was passed to env.step: for the
+    integer mode the integer repeated over the 5 columns, for force_discrete_action the vector before the argmax."""
+    save('g15_simple_tag_index_actions', **rollout('simple_tag', range(16), 25, actions='index'))
+    save('g15_simple_spread_index_actions', **rollout('simple_spread', range(8), 25, init=dense_init, actions='index'))
+    save('g16_simple_tag_force_discrete', **rollout('simple_tag', range(16), 25, actions='force'))
+    save('g16_simple_push_force_discrete', **rollout('simple_push', range(8), 25, init=dense_init, actions='force'))
+
+
 def hier_rest():
     for name, n, T in HIER_REST:
         save('h_' + name, **rollout_hier(name, range(n), T, actions='softmax'))
@@ -503,5 +526,7 @@ def hier_rest():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'hier_rest':     # only the fixtures added in round 2
         hier_rest()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'discrete':
+        discrete_cases()
     else:
         main()

@@ -528,3 +528,48 @@ def test_oracle_c_noise_bit_exact(golden_dir, name, mk):
             assert np.array_equal(np.stack([a.comm for a in env.agents]), g['comm'][s, t])
             assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]) and np.array_equal(np.asarray(rew_n, float), g['rew'][s, t])
 
+
+DECODE_CASES = [('g15_simple_tag_index_actions', O.simple_tag_spec, 'index'),
+                ('g15_simple_spread_index_actions', O.simple_spread_spec, 'index'),
+                ('g16_simple_tag_force_discrete', O.simple_tag_spec, 'force'),
+                ('g16_simple_push_force_discrete', O.simple_push_spec, 'force')]
+
+
+@pytest.mark.parametrize('name,mk,mode', DECODE_CASES)
+def test_oracle_non_default_action_decodes_bit_exact(golden_dir, name, mk, mode):
+    """environment.py:176-187: env.discrete_action_input (one integer per agent; 1/2 -> u[0] = -1/+1, 3/4 -> u[1] =
+    -1/+1, anything else no force) and env.force_discrete_action (argmax -> one-hot, first maximum).  The fixtures
+    hold what was passed to env.step; serial and vectorised restatement against the reference's trajectories."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    goal = np.maximum(g['goal'], 0)
+    bo = O.BatchedOracle(spec, discrete_action_input=mode == 'index', force_discrete_action=mode == 'force')
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    for t in range(T):
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, np.moveaxis(g['act'][:, t], 0, -1), None, goal=goal)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+    for s in range(min(S, 4)):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.discrete_action_input = mode == 'index'
+        env.force_discrete_action = mode == 'force'
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        env.goal = max(int(g['goal'][s]), 0)
+        for t in range(T):
+            acts = [int(a[0]) for a in g['act'][s, t]] if mode == 'index' else [a.copy() for a in g['act'][s, t]]
+            obs_n, rew_n, _, _ = env.step(acts)
+            p, v = env.get_state()
+            assert np.array_equal(p, g['pos'][s, t]) and np.array_equal(v, g['vel'][s, t]), (name, s, t)
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
+            if mode == 'force':      # in place, like the reference: the caller's arrays are one-hot afterwards
+                assert all(sorted(a) == [0, 0, 0, 0, 1] for a in acts)
+    if mode == 'index':
+        k = g['act'][:, :, :, 0]
+        assert set(np.unique(k)) == set(range(8))                       # incl. 0 and the out-of-range 5..7
+    else:
+        a = g['act']
+        assert ((a == a.max(-1, keepdims=True)).sum(-1) > 1).any()      # ties: the first maximum decides
