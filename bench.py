@@ -71,13 +71,14 @@ OTHER_CONFIGS = (('simple_spread_64k_f64', 500, 50), ('scaled_tag_256k_f32', 100
 def algorithmic_elems(env, with_info=True):
     """compulsory elements moved per env-step:
     act rows (5A, + dim_c per non-silent agent) + 2E pos rd + 2A vel rd + 4A pos,vel wr + sum obs_dim
-    + A reward + A*info_w (+ 2A leader_force wr and A*dim_c comm wr in a command hierarchy)."""
+    + A reward + A*info_w (+ 2A leader_force wr in a command hierarchy and dim_c comm wr per SPEAKING agent: a silent
+    agent's state.c stays the zeros it holds, MPE_FLAG_SILENT_COMM_ZERO)."""
     w = env.world
     A, E = len(w.agents), len(w.entities)
     obs = sum(s.shape[0] for s in env.observation_space)
     info_w = w.info.shape[1] if (with_info and w.info is not None and env.info_callback is not None) else 0
-    # agent.state.c of every agent is rewritten each step once any agent speaks (core.py:224-230)
-    extra = (2 * A if w.lforce is not None else 0) + (A * w.dim_c if any(not a.silent for a in w.agents) else 0)
+    # agent.state.c of a speaking agent is rewritten each step (core.py:224-230); a silent one's rows keep their zeros
+    extra = (2 * A if w.lforce is not None else 0) + w.dim_c * sum(1 for a in w.agents if not a.silent)
     moving = sum(1 for a in w.agents if a.movable)           # only movable agents have / update a velocity
     pos_rd = 2 * E if moving else 0                          # simple_crypto: nobody moves, nothing looks at positions
     return sum(w.act_dims) + pos_rd + 2 * moving + 4 * moving + obs + A + A * info_w + extra

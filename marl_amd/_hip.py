@@ -26,10 +26,11 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 8
+ABI_VERSION = 9
 FLAG_FORCE_TILE = 1
 FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
 FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
+FLAG_SILENT_COMM_ZERO = 8   # silent agents' comm rows already hold zeros: the step does not rewrite them
 SPLIT_MAX_ENVS = 32768
 ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA = 0, 1, 2
 

@@ -71,9 +71,12 @@ class AgentState(EntityState):
 
     @c.setter
     def c(self, value):
-        r = self._e._world.comm[self._e._index]
+        w = self._e._world
+        r = w.comm[self._e._index]
         r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], r.shape[0]).t())
-        self._e._world.mark_dirty()      # observations of the speaking scenarios read other.state.c
+        w.mark_dirty()      # observations of the speaking scenarios read other.state.c
+        if self._e.silent:  # the next step sets it back to zeros (core.py:226-227): World._clean_silent_comm
+            w._silent_comm_dirty = True
 
 
 class Action(object):
@@ -275,17 +278,31 @@ class World(object):
         self._desc = None
         # agent.state.c is only maintained on device when somebody speaks
         self._comm_arg = self.comm if (self.dim_c and not all(a.silent for a in self.agents)) else None
-        self._buf = _hip.Buffers(pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, comm=self._comm_arg)
+        # world.comm was allocated as zeros and only the step kernels (and AgentState.c's setter, which says so) write
+        # it: the rows of silent agents hold their zeros(dim_c) already, the step need not rewrite them every time
+        self._silent_comm_dirty = False
+        self._buf = _hip.Buffers(flags=_hip.FLAG_SILENT_COMM_ZERO, pos=self.pos, vel=self.vel, lforce=self.lforce,
+                                 goal=self.goal, comm=self._comm_arg)
         self.mark_dirty()
         return self
 
     def set_flags(self, flags):
         """Per-call hints passed in ``mpe_buffers.flags`` (e.g. ``_hip.FLAG_FORCE_TILE``: run the generic LDS-tile
         kernel for a world that has a register-resident one).  The statistics rows depend on the kernel chosen."""
-        self._buf.flags = int(flags)
+        self._buf.flags = int(flags) | _hip.FLAG_SILENT_COMM_ZERO
         if self.stats is not None:
             self.stats = None
             self.enable_stats()
+
+    def _clean_silent_comm(self):
+        """core.py:226-227: a step leaves agent.state.c of a silent agent at zeros(dim_c).  The kernels are told not to
+        rewrite those rows (FLAG_SILENT_COMM_ZERO); after a write through AgentState.c's setter they are zeroed here, in
+        front of the next step."""
+        if self._silent_comm_dirty:
+            for i, a in enumerate(self.agents):
+                if a.silent and self.dim_c:
+                    self.comm[i].zero_()
+            self._silent_comm_dirty = False
 
     def mark_dirty(self):
         """Call after writing world.pos / world.vel directly (setters on entity.state do it)."""
@@ -386,6 +403,7 @@ class World(object):
         b.cnoise = self._cnoise_ptr()
         b.info = self.info.data_ptr() if (want_info and self.info.numel()) else None
         b.stats = _hip.ptr(self.stats)
+        self._clean_silent_comm()
         self._flip_obs()
         with _hip.on_device(self.device):
             _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_env_step')
@@ -436,6 +454,7 @@ class World(object):
 
     def invalidate_descriptor(self):
         self._desc = None
+        self._silent_comm_dirty = True      # an agent may have turned silent: its rows must read zeros again
 
     def _cnoise_ptr(self):
         """Standard normals for c_noise (core.py:229), [A, dim_c, B]: ``world.cnoise`` if the caller set it
@@ -472,6 +491,7 @@ class World(object):
         b = self._buf
         b.act, b.noise = self.act.data_ptr(), nptr
         b.cnoise = self._cnoise_ptr()
+        self._clean_silent_comm()
         with _hip.on_device(self.device):
             _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_world_step')
         self.mark_dirty()

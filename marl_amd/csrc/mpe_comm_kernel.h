@@ -66,9 +66,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, comm
     if (p.comm != nullptr) {  // core.py:226-230
       const Win<T> wcomm(p.comm + blk0, ld);
 #pragma unroll
-      for (int a = 0; a < A; ++a)
+      for (int a = 0; a < A; ++a) {
+        if (!speaks(a) && !rewrite_silent_comm(p)) continue;
 #pragma unroll
         for (int k = 0; k < C; ++k) wcomm.st_state(a * C + k, lo, c[a][k]);
+      }
     }
 #pragma unroll
     for (int a = M0; a < A; ++a) {  // environment.py:188-196, core.py:211-222 (nothing collides)

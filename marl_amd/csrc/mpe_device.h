@@ -62,8 +62,18 @@ struct KParams {
   T *pos, *vel, *comm, *lforce, *obs, *rew, *info;
   double *stats;
   int64_t B, ld;
+  uint32_t flags;  // mpe_buffers.flags (MPE_FLAG_*): the kernels read MPE_FLAG_SILENT_COMM_ZERO
   DevDesc<T> d;
 };
+
+// agent.state.c of a SILENT agent is zeros(dim_c) after every step (core.py:226-227).  A caller whose comm buffer already
+// holds zeros in those rows says so with MPE_FLAG_SILENT_COMM_ZERO and the step leaves them alone: in the hierarchy worlds
+// they are 5-10 % of the rows a step writes and, as default-policy stores next to the nontemporal observation stream, cost
+// twice their share (S1L2F4_MovingTarget 1 Mi envs f32: 361 -> 289 us, L1F2_3Targets f64: 212 -> 172 us).
+template <typename T>
+__device__ __forceinline__ bool rewrite_silent_comm(const KParams<T> &p) {
+  return (p.flags & MPE_FLAG_SILENT_COMM_ZERO) == 0;
+}
 
 // Streaming (write-once) outputs -- observations, rewards, info -- use nontemporal stores so they do
 // not displace the env state (pos/vel, re-read every step) from L2 / Infinity Cache.  Measured on

@@ -506,6 +506,7 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
     return MPE_ERR_ALIGN;
   p.B = B;
   p.ld = ld;
+  p.flags = b->flags;
   to_device_desc<T>(h, p.d);
   return MPE_OK;
 }

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
       wpos.st_state(2 * a, lo, px[a]);
       wpos.st_state(2 * a + 1, lo, py[a]);
     }
-    if (p.comm != nullptr) {  // core.py:226-227
+    if (p.comm != nullptr && rewrite_silent_comm(p)) {  // core.py:226-227
       const Win<T> wcomm(p.comm + blk0, ld);
       for (int r = 0; r < A * d.dim_c; ++r) wcomm.st_state(r, lo, T(0));
     }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * A) void split_kernel(const KParams<T> p) {
     wvel.st_state(2 * me + 1, lo, mvy);
     wpos.st_state(2 * me, lo, mpx);
     wpos.st_state(2 * me + 1, lo, mpy);
-    if (p.comm != nullptr) {  // core.py:226-227
+    if (p.comm != nullptr && rewrite_silent_comm(p)) {  // core.py:226-227
       const Win<T> wcomm(p.comm + blk0, ld);
       for (int r = me * d.dim_c; r < (me + 1) * d.dim_c; ++r) wcomm.st_state(r, lo, T(0));
     }

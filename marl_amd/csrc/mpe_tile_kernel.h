@@ -316,6 +316,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         }
         if (p.comm != nullptr && active) {  // core.py:226-230 (c_noise is rejected on the host)
           const bool mute = !HIER || bit(d.silent, a);
+          if (mute && !rewrite_silent_comm(p)) continue;
           for (int c = 0; c < d.dim_c; ++c)
             p.comm[(int64_t)(a * d.dim_c + c) * ld + env] = mute ? T(0) : state_c<T, DO_STEP>(p, a, c, env);
         }

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
       const Win<T> wcomm(p.comm + blk0, ld);
 #pragma unroll
       for (int k = 0; k < C; ++k) wcomm.st_state(k, lo, c0[k]);
+      if (rewrite_silent_comm(p)) {
 #pragma unroll
-      for (int r = C; r < A * C; ++r) wcomm.st_state(r, lo, T(0));
+        for (int r = C; r < A * C; ++r) wcomm.st_state(r, lo, T(0));
+      }
     }
     T Fx[A], Fy[A];
 #pragma unroll

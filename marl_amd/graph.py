@@ -57,6 +57,7 @@ class CapturedSteps(object):
     def replay(self):
         """Runs the K steps; the world's Python-side bookkeeping ends up as after K ``env.step`` calls."""
         w = self.env.world
+        w._clean_silent_comm()
         self.graph.replay()
         w._obs_slot = self._slot_after
         w.obs, w.obs_views = w._obs_pair[w._obs_slot], w._views_pair[w._obs_slot]
@@ -148,6 +149,7 @@ class CapturedTrainSteps(object):
         self.ctr.fill_(delta - (1 << 32) if delta >= (1 << 31) else delta)
         for b, base in zip(self.buffers, self._base_idx):
             b.device_cursor().fill_((b._next_idx - base) % b._maxsize)
+        w._clean_silent_comm()
         self.graph.replay()
         for b in self.buffers:
             b.device_cursor().zero_()                  # eager add_all(cursors=True) calls see no offset

@@ -234,3 +234,77 @@ def test_c_noise_through_the_python_api():
     noise = (w.agents[1].state.c - action_n[1][:, 5:]) / 0.5
     assert abs(float(noise.mean())) < 0.05 and abs(float(noise.std()) - 1.0) < 0.05
 
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('flags', [0, 1], ids=['register_kernel', 'tile_kernel'])
+@pytest.mark.parametrize('name', ['h_S1L2F2_10Targets_wide', 'h_L1F2_3Targets_100observe', 'm_S1L2F4_MovingTarget',
+                                  'm_L1F4_MovingTarget', 'g13_simple_world_comm', 'g10_simple_speaker_listener',
+                                  'g11_simple_reference'])
+def test_silent_comm_zero_flag_leaves_silent_rows_alone(golden_dir, name, flags, dtype):
+    """MPE_FLAG_SILENT_COMM_ZERO: agent.state.c of a silent agent is zeros(dim_c) after every step (core.py:226-227); with
+    the flag the caller vouches that those rows hold zeros already and the step does not touch them (here: a sentinel
+    survives), the speaking agents' rows and every other output are bit-identical to a step without the flag, which
+    writes the zeros whatever the rows held."""
+    from tests.gpu_util import set_call_flags
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    spec = (O.hier_spec_from_golden(g) if name[0] in 'hm' else
+            {'g13': O.simple_world_comm_spec, 'g10': O.speaker_listener_spec, 'g11': O.simple_reference_spec}[name[:3]]())
+    S = g['act'].shape[0]
+    A, C = spec.n_agents, spec.dim_c
+    act = dev(np.ascontiguousarray(g['act'][:, 0].T), dtype)
+    outs = []
+    for extra in (0, 8):
+        set_call_flags(flags | extra)
+        try:
+            sim = HipSim(spec, S, dtype)
+            goal = g['goal'].T[:spec.goal_rows] if 'goal' in g.files and spec.goal_rows else None
+            sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'), goal,
+                          golden_soa(g, 'lforce0') if 'lforce0' in g.files else None)
+            comm = torch.full((A, C, S), 7.5, dtype=dtype, device='cuda')
+            sim.env_step(act, comm=comm)
+            torch.cuda.synchronize()
+            outs.append((comm.clone(), sim.pos.clone(), sim.vel.clone(), sim.obs.clone(), sim.rew.clone(), sim.info.clone(),
+                         None if sim.lforce is None else sim.lforce.clone()))
+        finally:
+            set_call_flags(0)
+    (c0, *rest0), (c1, *rest1) = outs
+    for i in range(A):
+        if spec.silent[i]:
+            assert (c0[i] == 0).all() and (c1[i] == 7.5).all(), i
+        else:
+            assert torch.equal(c0[i], c1[i]) and not (c0[i] == 7.5).all(), i
+    for x, y in zip(rest0, rest1):
+        assert (x is None and y is None) or torch.equal(x.nan_to_num(nan=123.0), y.nan_to_num(nan=123.0))
+    assert lib.mpe_stats_rows(sim.desc, S, 4, 16) == -6          # an unknown flag bit: MPE_ERR_ARG
+
+
+def test_world_keeps_silent_comm_rows_zero_without_rewriting_them():
+    """The Python World passes the flag (its comm buffer starts as zeros); a write through AgentState.c's setter on a
+    silent agent is undone in front of the next step, like the reference's state.c = zeros (core.py:226-227), and a
+    graph replay does the same."""
+    from marl_amd import _hip, make_env
+    from marl_amd.graph import CapturedSteps
+    env = make_env('S1L2F2_10Targets_wide', benchmark=True, num_envs=300, dtype=torch.float64, seed=3)
+    env.reset()
+    w = env.world
+    assert w._buf.flags & _hip.FLAG_SILENT_COMM_ZERO
+    w.set_flags(_hip.FLAG_FORCE_TILE)
+    assert w._buf.flags == _hip.FLAG_FORCE_TILE | _hip.FLAG_SILENT_COMM_ZERO
+    w.set_flags(0)
+    acts = [w.new_action_buffer() for _ in range(3)]
+    for a in acts:
+        a.copy_(torch.rand(a.shape, dtype=torch.float64, device='cuda'))
+    follower, leader = w.agents[0], w.agents[2]
+    assert follower.silent and not leader.silent
+    follower.state.c = np.arange(1.0, 8.0)
+    assert (follower.state.c == torch.arange(1.0, 8.0, dtype=torch.float64, device='cuda')).all()
+    env.step(acts[0])
+    assert (follower.state.c == 0).all()
+    assert torch.equal(leader.state.c.t(), acts[0][w.act_row0[2] + 5:w.act_row0[2] + 12])
+    cap = CapturedSteps(env, acts)
+    follower.state.c = np.ones(7)
+    cap.replay()
+    torch.cuda.synchronize()
+    assert (follower.state.c == 0).all()
+    assert torch.equal(leader.state.c.t(), acts[2][w.act_row0[2] + 5:w.act_row0[2] + 12])
