@@ -217,3 +217,48 @@ class MultiAgentEnv(object):
 
     def render(self, mode='human'):
         raise NotImplementedError('rendering (environment.py:216-298) is out of scope for the batched simulator')
+
+
+class BatchMultiAgentEnv(object):
+    """multiagent/environment.py:326-373: the reference's own wrapper around a list of envs, flat concatenation of the
+    per-env lists (``n`` = sum of the envs' ``n``; spaces = the first env's).  Here every member is itself a batched
+    MultiAgentEnv, so the wrapper only matters to callers that drive several worlds (different scenarios or seeds)
+    through one ``step``.  The reference's ``step(action_n, time)`` forwards ``time`` to ``MultiAgentEnv.step``, which
+    does not take it (a TypeError there); it is accepted and ignored here.  Like the reference, ``info_n`` comes back
+    empty (:360) and nothing is rendered."""
+    metadata = {'runtime.vectorized': True, 'render.modes': []}
+
+    def __init__(self, env_batch):
+        self.env_batch = env_batch
+
+    @property
+    def n(self):
+        return int(np.sum([env.n for env in self.env_batch]))
+
+    @property
+    def action_space(self):
+        return self.env_batch[0].action_space
+
+    @property
+    def observation_space(self):
+        return self.env_batch[0].observation_space
+
+    def step(self, action_n, time=None):
+        obs_n, reward_n, done_n, info_n = [], [], [], {'n': []}
+        i = 0
+        for env in self.env_batch:
+            obs, reward, done, _ = env.step(action_n[i:(i + env.n)])
+            i += env.n
+            obs_n += obs
+            reward_n += reward
+            done_n += done
+        return obs_n, reward_n, done_n, info_n
+
+    def reset(self):
+        obs_n = []
+        for env in self.env_batch:
+            obs_n += env.reset()
+        return obs_n
+
+    def render(self, mode='human', close=True):
+        raise NotImplementedError('rendering (environment.py:216-298) is out of scope for the batched simulator')

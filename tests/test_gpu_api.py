@@ -573,3 +573,25 @@ def test_ambiguous_action_tensor_shape_is_decided_by_the_row_stride():
     o3 = [o.clone() for o in env.step(soa)[0]]
     for a, b, c in zip(o1, o2, o3):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_batch_multi_agent_env_concatenates_member_envs():
+    """environment.py:326-373: n, spaces, step and reset of the list wrapper, over two batched worlds of different seeds."""
+    from marl_amd import make_env
+    from marl_amd.environment import BatchMultiAgentEnv
+    B = 96
+    envs = [make_env('simple_tag', benchmark=True, num_envs=B, dtype=torch.float64, seed=s) for s in (1, 2)]
+    ref = [make_env('simple_tag', benchmark=True, num_envs=B, dtype=torch.float64, seed=s) for s in (1, 2)]
+    batch = BatchMultiAgentEnv(envs)
+    assert batch.n == 8 and batch.action_space is envs[0].action_space and batch.observation_space is envs[0].observation_space
+    obs_n = batch.reset()
+    want = ref[0].reset() + ref[1].reset()
+    assert len(obs_n) == 8 and all(torch.equal(a, b) for a, b in zip(obs_n, want))
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    action_n = [torch.rand(B, 5, generator=gen, device='cuda', dtype=torch.float64) for _ in range(8)]
+    obs_n, rew_n, done_n, info_n = batch.step(action_n, 0)
+    o0, r0, d0, _ = ref[0].step(action_n[:4])
+    o1, r1, d1, _ = ref[1].step(action_n[4:])
+    assert all(torch.equal(a, b) for a, b in zip(obs_n, o0 + o1)) and all(torch.equal(a, b) for a, b in zip(rew_n, r0 + r1))
+    assert len(done_n) == 8 and info_n == {'n': []}
+    assert not torch.equal(obs_n[0], obs_n[4])                       # two different worlds
