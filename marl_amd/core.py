@@ -131,13 +131,27 @@ class Agent(Entity):
         self.u_range = 1.0
         self.state = AgentState(self)
         self.action = Action()
-        self.action_callback = None
+        self._action_callback = None
         # fork's command hierarchy (set by the L1F*/S1L* scenarios, L1F2_3Targets_100observe.py:36-70)
         self.adversary = False
         self.advleader = False
         self.advsuperleader = False
         self.force_id = -1
         self.forced_id = -1
+
+    @property
+    def action_callback(self):
+        """core.py:83: a scripted agent's ``callback(agent, world) -> Action``; World.step asks it for the agent's action
+        (core.py:126-127) and the env leaves the agent out of its lists (world.policy_agents).  Batched: ``action.u`` is
+        ``[B, 2]`` (or anything that broadcasts to it), the force as it stands; ``action.c`` ``[B, dim_c]`` for a
+        speaking agent."""
+        return self._action_callback
+
+    @action_callback.setter
+    def action_callback(self, cb):
+        self._action_callback = cb
+        if self._world is not None:
+            self._world.invalidate_descriptor()      # a scripted agent's force takes no sensitivity
 
     @property
     def leader_force(self):
@@ -294,6 +308,28 @@ class World(object):
             self.stats = None
             self.enable_stats()
 
+    def _run_scripted(self):
+        """core.py:126-127: ``agent.action = agent.action_callback(agent, self)`` for every scripted agent, in agent
+        order, in front of the step kernels; the action lands in the agent's own rows of the action buffer."""
+        rows = None
+        for a in self.agents:
+            cb = a.action_callback
+            if cb is None:
+                continue
+            if rows is None:
+                rows = self.act.view(-1, self.num_envs) if self.act.dim() == 3 else self.act
+            a.action = action = cb(a, self)
+            r0 = self.act_row0[a._index]
+            if a.movable:
+                u = torch.as_tensor(action.u, dtype=self.dtype, device=self.device).expand(self.num_envs, 2)
+                rows[r0:r0 + 5].zero_()
+                rows[r0 + 1].copy_(u[:, 0])
+                rows[r0 + 3].copy_(u[:, 1])
+                r0 += 5
+            if not a.silent:
+                c = torch.as_tensor(action.c, dtype=self.dtype, device=self.device).expand(self.num_envs, self.dim_c)
+                rows[r0:r0 + self.dim_c].copy_(c.t())
+
     def _clean_silent_comm(self):
         """core.py:226-227: a step leaves agent.state.c of a silent agent at zeros(dim_c).  The kernels are told not to
         rewrite those rows (FLAG_SILENT_COMM_ZERO); after a write through AgentState.c's setter they are zeroed here, in
@@ -398,6 +434,7 @@ class World(object):
         d = self.descriptor()
         keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_env_step_' + _hip.suffix(self.dtype))
+        self._run_scripted()
         b = self._buf
         b.act, b.noise = self.act.data_ptr(), nptr
         b.cnoise = self._cnoise_ptr()
@@ -434,9 +471,12 @@ class World(object):
         d.n_target_obs = int(getattr(self, 'n_target_obs', 3))
         for i, a in enumerate(self.agents):
             d.c_noise[i] = a.c_noise if a.c_noise else 0.0            # core.py:229
-            if a.action_callback is not None:
-                raise NotImplementedError('scripted agents (action_callback) are outside the HIP hot path')
             d.accel[i] = 5.0 if a.accel is None else a.accel          # environment.py:193-196
+            if a.action_callback is not None:
+                # core.py:126-127,143-149: the callback's u IS the force; the sensitivity belongs to the env's decode of
+                # policy agents.  _run_scripted() writes u into the agent's action rows as (0, ux, 0, uy, 0), which the
+                # kernels' decode (a[1] - a[2], a[3] - a[4]) * accel returns bit for bit with accel = 1
+                d.accel[i] = 1.0
             d.max_speed[i] = -1.0 if a.max_speed is None else a.max_speed
             d.u_noise[i] = a.u_noise if a.u_noise else 0.0            # core.py:147
             d.adversary[i] = int(bool(getattr(a, 'adversary', False)))
@@ -488,6 +528,7 @@ class World(object):
         d = self.descriptor()
         keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_world_step_' + _hip.suffix(self.dtype))
+        self._run_scripted()
         b = self._buf
         b.act, b.noise = self.act.data_ptr(), nptr
         b.cnoise = self._cnoise_ptr()

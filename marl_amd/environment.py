@@ -5,6 +5,10 @@
     obs_n = env.reset()                       # list of n tensors [B, obs_dim_i]
     obs_n, reward_n, done_n, info_n = env.step(action_n)
 
+Agents with an ``action_callback`` are scripted (core.py:83,126-127): ``World.step`` asks the callback for their action
+and the env's ``n``, spaces, ``action_n``, ``obs_n``, ``reward_n`` and ``info_n`` cover the other agents only
+(``world.policy_agents``); set the callbacks before constructing the env.
+
 ``action_n``: list of n tensors ``[B, 5]`` (soft one-hot Discrete(5), environment.py:188-190; ``[B, 5 +
 dim_c]`` for a non-silent agent, whose space is MultiDiscrete: 5 physical entries then the dim_c comm
 entries, environment.py:161-168), one tensor ``[B, n, 5]``, or one contiguous tensor ``[n, 5, B]`` /
@@ -75,8 +79,12 @@ class MultiAgentEnv(object):
             self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf, shape=(obs_dim,), dtype=np.float32))
         self._own_act = world.act
         self._uniform = world._uniform_actions                              # world.act is [n,5,B]
-        self.action_views = [world.act_rows[r0:r0 + n].t()                  # [B,act_dim] views, strides (1,B)
-                             for r0, n in zip(world.act_row0, world.act_dims)]
+        # world index of every policy agent (core.py:115-116): scripted agents own rows of the action buffer and of the
+        # outputs too, but the env's lists skip them (environment.py:21-22,96-110)
+        self._pidx = [a._index for a in self.agents]
+        self._all_policy = len(self._pidx) == len(world.agents)
+        self.action_views = [world.act_rows[world.act_row0[i]:world.act_row0[i] + world.act_dims[i]].t()
+                             for i in self._pidx]                           # [B,act_dim] views, strides (1,B)
         self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=world.device)
         self._empty_info = [{} for _ in range(self.n)]
 
@@ -99,10 +107,15 @@ class MultiAgentEnv(object):
             # environment.py:200-208: the integer decode of a comm action never consumes its entry
             raise AssertionError('discrete_action_input with a speaking agent: the reference fails its own '
                                  '`assert len(action) == 0` (environment.py:208)')
-        if self._idx is None:
-            self._idx = torch.zeros(self.n, w.ld, dtype=torch.int32, device=w.device)
+        if self._idx is None:      # one row per WORLD agent (a scripted agent's stays 0; World.step fills its action rows)
+            self._idx = torch.zeros(len(w.agents), w.ld, dtype=torch.int32, device=w.device)
         idx = self._idx[:, :self.num_envs]
-        if torch.is_tensor(action_n) and action_n.dim() == 2:
+        if not self._all_policy:
+            if torch.is_tensor(action_n) or len(action_n) != self.n:
+                raise ValueError('need one action per policy agent (a list)')
+            for i, a in zip(self._pidx, action_n):
+                idx[i].copy_(torch.as_tensor(a, device=w.device).reshape(-1).expand(self.num_envs))
+        elif torch.is_tensor(action_n) and action_n.dim() == 2:
             if tuple(action_n.shape) == (self.num_envs, self.n) and self.num_envs != self.n:
                 action_n = action_n.t()
             if tuple(action_n.shape) != (self.n, self.num_envs):
@@ -122,6 +135,8 @@ class MultiAgentEnv(object):
 
     def _copy_actions(self, action_n):
         act = self.world.act
+        if not self._all_policy and torch.is_tensor(action_n):
+            raise ValueError('with scripted agents pass one action per POLICY agent (a list, environment.py:96-98)')
         soa = (torch.is_tensor(action_n) and action_n.dim() == act.dim() and tuple(action_n.shape) == tuple(act.shape)
                and action_n.dtype == act.dtype and action_n.device == act.device)
         if soa and act.dim() == 3 and tuple(action_n.shape) == (self.num_envs, self.n, 5):
@@ -162,14 +177,17 @@ class MultiAgentEnv(object):
 
     def step(self, action_n):
         self.agents = self.world.policy_agents
+        if len(self.agents) != self.n:
+            raise RuntimeError('the set of scripted agents changed: build a new MultiAgentEnv (n and the spaces are fixed '
+                               'at construction, environment.py:21-22)')
         self._set_actions(action_n)
         world = self.world
         if self._fused:
             world.env_step(want_info=self.info_callback is not None)
-            obs_n = list(world.obs_views)
-            reward_n = [world.rew[i] for i in range(self.n)]
+            obs_n = [world.obs_views[i] for i in self._pidx]
+            reward_n = [world.rew[i] for i in self._pidx]
             if self.info_callback is not None:
-                info_n = {'n': [self._scenario._format_info(world.info[i], self.agents[i]) for i in range(self.n)]}
+                info_n = {'n': [self._scenario._format_info(world.info[i], a) for i, a in zip(self._pidx, self.agents)]}
             else:
                 info_n = {'n': list(self._empty_info)}
         else:
@@ -191,7 +209,7 @@ class MultiAgentEnv(object):
         if self._fused:
             w = self.world
             w.gather_obs()
-            return list(w.obs_views)
+            return [w.obs_views[i] for i in self._pidx]
         return [self._get_obs(agent) for agent in self.agents]
 
     # -- environment.py:131-154 ------------------------------------------------------------------------

@@ -19,6 +19,8 @@ class CapturedSteps(object):
         if not env._fused:
             raise RuntimeError('CapturedSteps needs the fused step (built-in scenario callbacks)')
         w = env.world
+        if w.scripted_agents:
+            raise RuntimeError('CapturedSteps cannot record scripted agents (their action_callback is host code)')
         for a in action_seq:
             if not (torch.is_tensor(a) and tuple(a.shape) == tuple(w.act.shape) and a.stride() == env._own_act.stride()
                     and a.dtype == w.act.dtype and a.device == w.act.device):

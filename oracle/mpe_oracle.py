@@ -364,6 +364,10 @@ class SerialEnv:
         self.n = spec.n_agents
         self.goal = 0        # index of the goal landmark (agent.goal_a), GOAL_KINDS only
         self.goals = [0] * spec.n_agents   # agent.goal_b landmark index, COMM_KINDS only
+        # core.py:83,116-127: agents with an action_callback are scripted: World.step asks the callback for their action
+        # (its u is the force as it stands, no sensitivity) and the env's n / action_n / obs_n / reward_n / info_n cover the
+        # others only.  {agent index: callback(env, index) -> u (2-vector)}
+        self.scripted = {}
         self.discrete_action_input = False   # environment.py:31: the action is an integer
         self.force_discrete_action = False   # environment.py:33: argmax -> one-hot before the decode
 
@@ -885,11 +889,15 @@ class SerialEnv:
 
     # -- environment.py:92-117 ---------------------------------------------------------------
     def step(self, action_n):
-        for i, a in enumerate(self.agents):
-            self._decode_action(a, action_n[i])
+        policy = [i for i in range(self.n) if i not in self.scripted]      # world.policy_agents (core.py:115-116)
+        for j, i in enumerate(policy):
+            self._decode_action(self.agents[i], action_n[j])
+        for i, cb in self.scripted.items():                                  # core.py:126-127
+            self.agents[i].u = np.asarray(cb(self, i), dtype=np.float64)
+            self.agents[i].c_act = np.zeros(self.spec.dim_c)
         self.world_step()
         obs_n, rew_n, done_n, info_n = [], [], [], {'n': []}
-        for i in range(self.n):
+        for i in policy:
             obs_n.append(self.observation(i))
             rew_n.append(self.reward(i))
             done_n.append(False)
@@ -984,8 +992,10 @@ class BatchedOracle:
                 lf[i] = lf[i] + f
         return lf
 
-    def world_step(self, pos, vel, act, noise=None, return_lforce=False):
-        """act: [A,5,B] (all agents silent) or ragged rows [sum(act_dims), B] (environment.py:161-168)."""
+    def world_step(self, pos, vel, act, noise=None, return_lforce=False, scripted_u=None):
+        """act: [A,5,B] (all agents silent) or ragged rows [sum(act_dims), B] (environment.py:161-168).
+        scripted_u: {agent index: u [2, B]} for agents with an action_callback (core.py:126-127): the force as the
+        callback returned it, no sensitivity; their action rows are not looked at."""
         s, T = self.spec, self.dt
         A, E = s.n_agents, s.n_entities
         pos = np.array(pos, dtype=T)
@@ -1003,6 +1013,8 @@ class BatchedOracle:
                 sens = T(5.0 if s.accel[i] is None else s.accel[i])
                 a = self.physical_action(act[offs[i]:offs[i] + 5])
                 u = np.stack([(a[1] - a[2]) * sens, (a[3] - a[4]) * sens])
+                if scripted_u is not None and i in scripted_u:
+                    u = np.asarray(scripted_u[i], dtype=T)
                 if s.movable[i]:
                     if s.u_noise[i]:
                         u = u + np.asarray(noise[i], dtype=T) * T(s.u_noise[i])
@@ -1448,8 +1460,8 @@ class BatchedOracle:
                     info[i, 0], info[i, 1], info[i, 2], info[i, 3] = r, c, md, occ
         return obs, rew, (info if want_info else None)
 
-    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False, cnoise=None):
-        pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True)
+    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False, cnoise=None, scripted_u=None):
+        pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True, scripted_u=scripted_u)
         obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce,
                                       comm=self.comm_state(act, cnoise) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO, WORLD_COMM) else None)
         if return_lforce:

@@ -303,6 +303,98 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
     return res
 
 
+def _toward(target_of, gain, cap):
+    """A scripted agent's action_callback (core.py:83,126-127): a capped proportional controller towards the entity
+    target_of(world) returns.  The returned Action's u is used as the force as it stands (core.py:143-149: no
+    sensitivity, that is applied by the env's decode of POLICY agents only, environment.py:193-196)."""
+    from multiagent.core import Action
+
+    def cb(agent, world):
+        a = Action()
+        a.u = np.clip(gain * (target_of(world).state.p_pos - agent.state.p_pos), -cap, cap)
+        a.c = np.zeros(world.dim_c)
+        return a
+    return cb
+
+
+SCRIPTED = {
+    # name: (kind, {agent index: callback}, u_noise, init)
+    's1_simple_tag_scripted_prey': ('simple_tag', lambda: {3: _toward(lambda w: w.landmarks[0], 2.0, 4.0)}, None),
+    's2_simple_tag_scripted_chasers': ('simple_tag', lambda: {0: _toward(lambda w: w.agents[3], 4.0, 3.0),
+                                                             2: _toward(lambda w: w.agents[3], 1.5, 3.0)}, 0.3),
+}
+
+
+def rollout_scripted(name, seeds, T, init=None):
+    """World.step's scripted-agent loop (core.py:126-127): some agents carry an action_callback, the env then only
+    knows the others (world.policy_agents: n, spaces, action_n, obs_n, reward_n, info_n all skip the scripted ones,
+    environment.py:21-22,96-110).  'act' holds the policy agents' actions at their WORLD index (zeros elsewhere),
+    'u_scripted' what the callbacks returned; obs / rew / info are the env's lists, i.e. policy agents only."""
+    kind, mk, u_noise = SCRIPTED[name]
+    keys = ('pos0', 'vel0', 'obs0', 'act', 'noise', 'u_scripted', 'pos', 'vel', 'obs', 'rew', 'info')
+    out = {k: [] for k in keys}
+    for seed in seeds:
+        np.random.seed(seed)
+        S = TAG.Scenario()
+        world = S.make_world()
+        _shim(world)
+        cbs = mk()
+        for i, cb in cbs.items():
+            world.agents[i].action_callback = cb
+        if u_noise is not None:
+            for a in world.agents:
+                a.u_noise = u_noise
+        env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data)
+        A = len(world.agents)
+        policy = [i for i in range(A) if i not in cbs]
+        assert env.n == len(policy) and len(env.action_space) == len(policy)
+        obs0 = env.reset()
+        if init is not None:
+            init(world, np.random.RandomState(10_000 + seed))
+            obs0 = [env._get_obs(a) for a in env.agents]
+        pos0, vel0 = _state(world)
+        arng = np.random.RandomState(20_000 + seed)
+        ep = {k: [] for k in ('act', 'noise', 'u_scripted', 'pos', 'vel', 'obs', 'rew', 'info')}
+        for t in range(T):
+            logits = arng.randn(A, 5)
+            e = np.exp(logits - logits.max(axis=1, keepdims=True))
+            act = e / e.sum(axis=1, keepdims=True)
+            act[list(cbs)] = 0.0
+            s_t = 30_000 + 1000 * seed + t
+            np.random.seed(s_t)
+            noise = np.random.RandomState(s_t).randn(A, 2)
+            obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in policy])
+            assert len(obs_n) == len(rew_n) == len(info_n['n']) == len(policy)
+            pos, vel = _state(world)
+            u = np.zeros((A, 2))
+            for i in cbs:
+                u[i] = world.agents[i].action.u        # what World.step used (before noise)
+            ep['act'].append(act)
+            ep['noise'].append(noise)
+            ep['u_scripted'].append(u)
+            ep['pos'].append(pos.copy())
+            ep['vel'].append(vel.copy())
+            ep['obs'].append(np.concatenate(obs_n))
+            ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
+            ep['info'].append(np.stack([_info_row(x) for x in info_n['n']]))
+        out['pos0'].append(pos0)
+        out['vel0'].append(vel0)
+        out['obs0'].append(np.concatenate(obs0))
+        for k in ep:
+            out[k].append(np.stack(ep[k]))
+    res = {k: np.stack(v) for k, v in out.items()}
+    res['seeds'] = np.asarray(list(seeds))
+    res['scripted'] = np.asarray(sorted(cbs), np.int64)
+    res['u_noise'] = np.float64(0.0 if u_noise is None else u_noise)
+    return res
+
+
+def scripted_cases():
+    for name in SCRIPTED:
+        save(name, **rollout_scripted(name, range(16), 25))
+        save(name + '_dense', **rollout_scripted(name, range(16), 25, init=dense_init))
+
+
 COMM = {k: _load(REF + '/build/lib/multiagent/scenarios/%s.py' % k, 'ref_' + k)
         for k in ('simple_speaker_listener', 'simple_reference', 'simple_crypto',
                   'simple_world_comm')}                                                    # SURVEY 8f row f1, non-silent half
@@ -496,6 +588,7 @@ def main():
         save('m_' + name + '_crowd', **rollout_hier(name, range(16), 6, init=crowd_init))
     hier_rest()
     discrete_cases()
+    scripted_cases()
     kat_cases()
 
 
@@ -528,5 +621,7 @@ if __name__ == '__main__':
         hier_rest()
     elif len(sys.argv) > 1 and sys.argv[1] == 'discrete':
         discrete_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'scripted':
+        scripted_cases()
     else:
         main()

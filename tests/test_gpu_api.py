@@ -595,3 +595,93 @@ def test_batch_multi_agent_env_concatenates_member_envs():
     assert all(torch.equal(a, b) for a, b in zip(obs_n, o0 + o1)) and all(torch.equal(a, b) for a, b in zip(rew_n, r0 + r1))
     assert len(done_n) == 8 and info_n == {'n': []}
     assert not torch.equal(obs_n[0], obs_n[4])                       # two different worlds
+
+
+SCRIPTED_CASES = ['s1_simple_tag_scripted_prey', 's1_simple_tag_scripted_prey_dense',
+                  's2_simple_tag_scripted_chasers', 's2_simple_tag_scripted_chasers_dense']
+
+
+@pytest.mark.parametrize('name', SCRIPTED_CASES)
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=['f64', 'f32'])
+def test_scripted_agents_match_reference(golden_dir, name, dtype, tol):
+    """core.py:126-127 / environment.py:21-22 through the public API, built the way the reference's users build it
+    (scenario.make_world(), agent.action_callback = ..., MultiAgentEnv(world, ...)): the callbacks of
+    tests/golden/gen_golden.py:SCRIPTED restated on the batched state; 25 steps against the reference's trajectories
+    (f64 free-running <= 1e-9, f32 teacher-forced <= 1e-4), incl. what the callbacks returned and u_noise on top of it."""
+    import marl_amd.scenarios as scenarios
+    from marl_amd.core import Action
+    from marl_amd.environment import MultiAgentEnv
+    from marl_amd.graph import CapturedSteps
+    from tests.gpu_util import dev, golden_soa
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    S, T = g['act'].shape[:2]
+    un = float(g['u_noise'])
+
+    def toward(target_of, gain, cap):
+        def cb(agent, world):
+            a = Action()
+            a.u = torch.clamp(gain * (target_of(world).state.p_pos - agent.state.p_pos), -cap, cap)
+            a.c = torch.zeros(world.num_envs, world.dim_c, dtype=world.dtype, device=world.device)
+            return a
+        return cb
+    cbs = ({3: toward(lambda w: w.landmarks[0], 2.0, 4.0)} if name.startswith('s1_') else
+           {0: toward(lambda w: w.agents[3], 4.0, 3.0), 2: toward(lambda w: w.agents[3], 1.5, 3.0)})
+    assert sorted(cbs) == list(g['scripted'])
+    scen = scenarios.load('simple_tag.py').Scenario(num_envs=S, dtype=dtype, seed=1)
+    world = scen.make_world()
+    for i, cb in cbs.items():
+        world.agents[i].action_callback = cb
+    if un:
+        for a in world.agents:
+            a.u_noise = un
+        world.invalidate_descriptor()
+    env = MultiAgentEnv(world, scen.reset_world, scen.reward, scen.observation, scen.benchmark_data)
+    policy = [i for i in range(4) if i not in cbs]
+    assert env.n == len(policy) == len(env.action_space) == len(env.observation_space) == len(env.action_views)
+    assert [a._index for a in env.agents] == policy and [a._index for a in world.scripted_agents] == sorted(cbs)
+    assert len(env.reset()) == env.n
+
+    def set_state(p, v):
+        world.pos.copy_(dev(p, dtype))
+        world.vel.copy_(dev(v, dtype))
+        world.mark_dirty()
+    set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'))
+    obs0 = torch.cat([env._get_obs(a) for a in env.agents], 1)
+    np.testing.assert_allclose(_np(obs0), g['obs0'], rtol=0, atol=0 if dtype == torch.float64 else 1e-6)
+    for t in range(T):
+        if dtype == torch.float32 and t:
+            set_state(golden_soa(g, 'pos', t - 1), golden_soa(g, 'vel', t - 1))
+        if un:
+            world.noise = dev(golden_soa(g, 'noise', t), dtype)
+        obs_n, rew_n, done_n, info_n = env.step([dev(g['act'][:, t, i], dtype) for i in policy])
+        assert len(obs_n) == len(rew_n) == len(done_n) == len(info_n['n']) == env.n
+        for i in cbs:
+            u = _np(world.agents[i].action.u)
+            if dtype == torch.float64:
+                assert np.array_equal(u, g['u_scripted'][:, t, i])           # same IEEE operations as the reference
+            else:
+                np.testing.assert_allclose(u, g['u_scripted'][:, t, i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(_np(world.pos), golden_soa(g, 'pos', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(_np(world.vel), golden_soa(g, 'vel', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(_np(torch.cat(obs_n, 1)), g['obs'][:, t], rtol=tol, atol=tol)
+        if dtype == torch.float64:
+            np.testing.assert_allclose(_np(torch.stack(rew_n, 1)), g['rew'][:, t], rtol=0, atol=tol)
+            assert np.array_equal(_np(torch.stack(info_n['n'], 1)), g['info'][:, t, :, 0])
+    with pytest.raises(ValueError):                     # the SoA / [B, n, 5] forms would have to name the scripted rows
+        env.step(torch.zeros(S, env.n, 5, dtype=dtype, device='cuda'))
+    with pytest.raises(RuntimeError):
+        CapturedSteps(env, [world.new_action_buffer()])
+    # integer actions (environment.py:176-182) for the policy agents, the callbacks for the others: same as the one-hots
+    state = (world.pos.clone(), world.vel.clone())
+    world.noise = torch.zeros_like(world.vel) if un else None
+    k = torch.randint(0, 5, (env.n, S), device='cuda')
+    onehot = [torch.zeros(S, 5, dtype=dtype, device='cuda') for _ in range(env.n)]
+    for j in range(env.n):
+        for kk, slot in ((1, 2), (2, 1), (3, 4), (4, 3)):
+            onehot[j][k[j] == kk, slot] = 1.0
+    o1 = [o.clone() for o in env.step(onehot)[0]]
+    world.pos.copy_(state[0]); world.vel.copy_(state[1]); world.mark_dirty()
+    env.discrete_action_input = True
+    o2 = env.step([k[j] for j in range(env.n)])[0]
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)

@@ -573,3 +573,60 @@ def test_oracle_non_default_action_decodes_bit_exact(golden_dir, name, mk, mode)
     else:
         a = g['act']
         assert ((a == a.max(-1, keepdims=True)).sum(-1) > 1).any()      # ties: the first maximum decides
+
+
+def scripted_callbacks(name):
+    """The callbacks of tests/golden/gen_golden.py:SCRIPTED restated on (pos [E, 2, ...], agent index) -> u [2, ...]: capped
+    proportional controllers towards an entity."""
+    def toward(target, gain, cap):
+        return lambda pos, i: np.clip(gain * (pos[target] - pos[i]), -cap, cap)
+    if name.startswith('s1_'):
+        return {3: toward(4, 2.0, 4.0)}                  # the prey heads for landmark 0 (entity 4)
+    return {0: toward(3, 4.0, 3.0), 2: toward(3, 1.5, 3.0)}     # two of the three adversaries chase agent 3
+
+
+SCRIPTED_CASES = ['s1_simple_tag_scripted_prey', 's1_simple_tag_scripted_prey_dense',
+                  's2_simple_tag_scripted_chasers', 's2_simple_tag_scripted_chasers_dense']
+
+
+@pytest.mark.parametrize('name', SCRIPTED_CASES)
+def test_oracle_scripted_agents_bit_exact(golden_dir, name, monkeypatch):
+    """core.py:126-127 + environment.py:21-22: agents with an action_callback get their force from it (no sensitivity; the
+    u_noise of core.py:147 still applies) and disappear from the env's lists.  Serial and vectorised restatement against
+    the reference, incl. the recorded callback outputs."""
+    g = _load(golden_dir, name)
+    un = float(g['u_noise'])
+    spec = O.simple_tag_spec(u_noise=un if un else None)
+    cbs = scripted_callbacks(name)
+    assert sorted(cbs) == list(g['scripted'])
+    policy = [i for i in range(spec.n_agents) if i not in cbs]
+    S, T = g['act'].shape[:2]
+    rows = np.concatenate([np.arange(sum(spec.obs_dims[:i]), sum(spec.obs_dims[:i + 1])) for i in policy])
+    bo = O.BatchedOracle(spec)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    obs, _, _ = bo.observe(pos, vel)
+    assert np.array_equal(np.concatenate(obs, 0)[rows], g['obs0'].T)
+    for t in range(T):
+        u = {i: cb(pos, i) for i, cb in cbs.items()}
+        for i in cbs:
+            assert np.array_equal(u[i], g['u_scripted'][:, t, i].T), (name, t, i)
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, np.moveaxis(g['act'][:, t], 0, -1),
+                                               np.moveaxis(g['noise'][:, t], 0, -1) if un else None, scripted_u=u)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(np.concatenate(obs, 0)[rows], g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew[policy], g['rew'][:, t].T), (name, t)
+        assert np.array_equal(info[policy, 0], g['info'][:, t, :, 0].T), (name, t)
+    for s in range(4):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.scripted = {i: (lambda e, k, cb=cb: cb(np.stack([b.pos for b in e.bodies]), k)) for i, cb in cbs.items()}
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        for t in range(T):
+            if un:
+                monkeypatch.setattr(np.random, 'randn', _FixedNoise(g['noise'][s, t]))
+            obs_n, rew_n, done_n, info_n = env.step([g['act'][s, t, i] for i in policy])
+            assert len(obs_n) == len(policy)
+            p, v = env.get_state()
+            assert np.array_equal(p, g['pos'][s, t]) and np.array_equal(v, g['vel'][s, t]), (name, s, t)
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]) and np.array_equal(np.asarray(rew_n, float), g['rew'][s, t])
