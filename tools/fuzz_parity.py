@@ -1,0 +1,164 @@
+"""Differential fuzz of the HIP step against the CPU oracle on worlds no scenario file builds: random agent / landmark counts
+and random per-entity constants (sizes, masses, accel None or a value, max_speed None or a value, collide flags in
+irregular patterns, u_noise on some agents, damping / dt / contact constants), dense starts so that contacts happen.
+f64, every output of 3 steps within 1e-9 (NaN patterns equal).  Run on the GPU box from the repo root:
+    python tools/fuzz_parity.py [n_worlds] [seed]
+Prints one line per mismatch or refusal and a summary; exit status 1 if anything differs."""
+import dataclasses
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import mpe_oracle as O  # noqa: E402
+from marl_amd import _hip  # noqa: E402
+from tests.gpu_util import HipSim, dev, set_call_flags  # noqa: E402
+from tests.gpu_util_host import desc_from_spec  # noqa: E402,F401
+
+
+def random_hier(rng):
+    """A command hierarchy no scenario file builds: random counts, random who-commands-whom (several leaders on one
+    forced_id, silent leaders, a super-leader or none -- never sharing a force_id with a plain leader, which both sides
+    refuse), 3 or 7 commands, random radii / sizes / masses / speed limits / collide flags, both reward texts."""
+    A, L = int(rng.randint(2, 9)), int(rng.randint(1, 12))
+    pick = lambda p: rng.rand() < p
+    n_lead = int(rng.randint(1, max(2, A // 2 + 1)))
+    lead = [i >= A - n_lead for i in range(A)]
+    sup = [lead[i] and i == A - 1 and n_lead > 1 and pick(0.5) for i in range(A)]
+    ids = [1, 2, 3]
+    force_id, forced_id = [-1] * A, [-1] * A
+    for i in range(A):
+        if lead[i] and not sup[i]:
+            force_id[i] = int(rng.choice(ids[:2]))
+            if pick(0.3):
+                forced_id[i] = 3                     # a leader under the super-leader
+        elif sup[i]:
+            force_id[i] = 3
+        elif pick(0.8):
+            forced_id[i] = int(rng.choice(ids[:2]))
+    silent = [not lead[i] or pick(0.15) for i in range(A)]
+    if all(silent):
+        silent[A - 1] = False
+    return 'hier', O.ScenarioSpec(
+        kind=O.HIER_PURSUIT, n_agents=A, n_landmarks=L, adversary=[pick(0.85) for _ in range(A)],
+        size=[float(rng.uniform(0.04, 0.12)) for _ in range(A + L)],
+        accel=[None if pick(0.2) else float(rng.uniform(2, 5)) for _ in range(A)],
+        max_speed=[None if pick(0.2) else float(rng.uniform(0.5, 1.5)) for _ in range(A)],
+        collide=[bool(pick(0.8)) for _ in range(A + L)], movable=[True] * A + [False] * L, u_noise=[None] * A,
+        mass=[float(rng.choice([1.0, 0.5, 2.0])) for _ in range(A + L)], agent_pos_range=1.0, landmark_pos_range=1.0,
+        dim_c=int(rng.choice([3, 7])), silent=silent, force_id=force_id, forced_id=forced_id, advleader=lead,
+        advsuperleader=sup, obs_r=[float(rng.uniform(0.15, 0.8)) for _ in range(A)],
+        reward_variant=int(rng.randint(0, 2)), n_target_obs=3)
+
+
+def random_spec(rng):
+    kind = rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier'])
+    if kind == 'hier':
+        return random_hier(rng)
+    if kind == 'tag':
+        spec = O.simple_tag_spec(int(rng.randint(1, 7)), int(rng.randint(1, 5)), int(rng.randint(0, 6)))
+    elif kind == 'spread':
+        spec = O.simple_spread_spec(int(rng.randint(1, 7)), int(rng.randint(1, 7)))
+    elif kind == 'simple':
+        spec = O.simple_spec()
+    elif kind == 'adversary':
+        spec = O.simple_adversary_spec(int(rng.randint(2, 7)))
+    else:
+        n = int(rng.randint(2, 7))
+        spec = O.simple_push_spec(n, int(rng.randint(1, n)), int(rng.randint(1, 3)))
+    A, E = spec.n_agents, spec.n_entities
+    pick = lambda p: rng.rand() < p
+    rep = {}
+    if pick(0.7):
+        rep['size'] = [float(rng.uniform(0.02, 0.3)) for _ in range(E)]
+    if pick(0.5):
+        rep['mass'] = [float(rng.uniform(0.5, 3.0)) for _ in range(E)]
+    if pick(0.6):
+        rep['accel'] = [None if pick(0.3) else float(rng.uniform(1.0, 6.0)) for _ in range(A)]
+    if pick(0.6):
+        rep['max_speed'] = [None if pick(0.4) else float(rng.uniform(0.2, 2.0)) for _ in range(A)]
+    if pick(0.6):
+        rep['collide'] = [bool(pick(0.6)) for _ in range(E)]
+    if pick(0.4):
+        rep['u_noise'] = [None if pick(0.5) else float(rng.uniform(0.05, 0.5)) for _ in range(A)]
+    if pick(0.4):
+        rep.update(damping=float(rng.uniform(0.0, 0.5)), dt=float(rng.uniform(0.05, 0.2)),
+                   contact_force=float(rng.uniform(20, 200)), contact_margin=float(10 ** rng.uniform(-3, -2)))
+    return kind, dataclasses.replace(spec, **rep)
+
+
+def run(n_worlds, seed):
+    """-> (mismatching runs, worlds refused by mpe_desc_check, worlds per kind)"""
+    rng = np.random.RandomState(seed)
+    B, T = 257, 3
+    bad = refused = 0
+    kernels = {}
+    for w in range(n_worlds):
+        kind, spec = random_spec(rng)
+        d = desc_from_spec_or_none(spec)
+        if d is None:
+            refused += 1
+            continue
+        A, E = spec.n_agents, spec.n_entities
+        pos = rng.uniform(-0.45, 0.45, (E, 2, B))
+        vel = rng.uniform(-0.8, 0.8, (A, 2, B))
+        goal = rng.randint(0, max(spec.n_landmarks, 1), B)
+        hier = spec.kind == O.HIER_PURSUIT
+        lf0 = rng.uniform(-1, 1, (A, 2, B)) if hier and spec.has_leader_force else None
+        acts = [rng.rand(sum(spec.act_dims), B) if hier else rng.dirichlet(np.ones(5), (A, B)).transpose(0, 2, 1)
+                for _ in range(T)]
+        noises = [rng.randn(A, 2, B) for _ in range(T)]
+        has_noise = any(spec.u_noise)
+        bo = O.BatchedOracle(spec)
+        for flags in (0, 1):
+            set_call_flags(flags)
+            try:
+                sim = HipSim(spec, B, torch.float64)
+                sim.set_state(pos, vel, goal, lf0)
+                p, v = pos, vel
+                for t in range(T):
+                    sim.env_step(dev(acts[t], torch.float64), dev(noises[t], torch.float64) if has_noise else None)
+                    p, v, obs, rew, info = bo.env_step(p, v, acts[t], noises[t] if has_noise else None,
+                                                       goal=goal if spec.kind in O.GOAL_KINDS else None)
+                    got = sim.host()
+                    want = (p, v, np.concatenate(obs, 0), rew, info)
+                    for nm, x, y in zip(('pos', 'vel', 'obs', 'rew', 'info'), got, want):
+                        if y is None or x.size == 0:
+                            continue
+                        y = np.asarray(y, np.float64).reshape(x.shape)
+                        ok = np.array_equal(np.isnan(x), np.isnan(y)) and np.nanmax(np.abs(x - y), initial=0.0) <= 1e-9
+                        if not ok:
+                            bad += 1
+                            err = np.nanmax(np.abs(x - y), initial=0.0)
+                            print('MISMATCH world %d (%s A=%d L=%d) flags=%d step %d %s: max err %.3e nan %d/%d   spec=%r'
+                                  % (w, kind, A, spec.n_landmarks, flags, t, nm, err, np.isnan(x).sum(), np.isnan(y).sum(), spec),
+                                  flush=True)
+                            raise StopIteration
+            except StopIteration:
+                pass
+            finally:
+                set_call_flags(0)
+        kernels[kind] = kernels.get(kind, 0) + 1
+    return bad, refused, {str(k): v for k, v in kernels.items()}
+
+
+def main():
+    n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad, refused, kinds = run(n_worlds, seed)
+    print('worlds %d (refused by mpe_desc_check: %d), by kind %s, mismatching (world, kernel) runs: %d'
+          % (n_worlds, refused, kinds, bad))
+    sys.exit(1 if bad else 0)
+
+
+def desc_from_spec_or_none(spec):
+    try:
+        return desc_from_spec(spec)
+    except AssertionError:
+        return None
+
+
+if __name__ == '__main__':
+    main()
