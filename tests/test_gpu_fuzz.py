@@ -17,4 +17,6 @@ def test_random_worlds_match_the_oracle():
     spec.loader.exec_module(mod)
     bad, refused, kinds = mod.run(400, 0)
     assert bad == 0 and refused == 0
-    assert set(kinds) == {'tag', 'spread', 'simple', 'adversary', 'push', 'hier'} and min(kinds.values()) >= 20
+    bad, _, _ = mod.run(30, 1, perturb=1e-6)            # negative control: a 1e-6 change of the damping is noticed
+    assert bad >= 50
+    assert set(kinds) == {'tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'wcomm'} and min(kinds.values()) >= 20

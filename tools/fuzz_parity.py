@@ -54,13 +54,16 @@ def random_hier(rng):
 
 
 def random_spec(rng):
-    kind = rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier'])
+    kind = rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier', 'wcomm'])
     if kind == 'hier':
         return random_hier(rng)
     if kind == 'tag':
         spec = O.simple_tag_spec(int(rng.randint(1, 7)), int(rng.randint(1, 5)), int(rng.randint(0, 6)))
     elif kind == 'spread':
         spec = O.simple_spread_spec(int(rng.randint(1, 7)), int(rng.randint(1, 7)))
+    elif kind == 'wcomm':     # simple_world_comm.py: tag physics, food, two forests, a speaking leader (agent 0)
+        spec = O.simple_world_comm_spec(int(rng.randint(1, 6)), int(rng.randint(1, 4)), int(rng.randint(0, 3)),
+                                        int(rng.randint(1, 4)), 2)
     elif kind == 'simple':
         spec = O.simple_spec()
     elif kind == 'adversary':
@@ -89,8 +92,9 @@ def random_spec(rng):
     return kind, dataclasses.replace(spec, **rep)
 
 
-def run(n_worlds, seed):
-    """-> (mismatching runs, worlds refused by mpe_desc_check, worlds per kind)"""
+def run(n_worlds, seed, perturb=0.0):
+    """-> (mismatching runs, worlds refused by mpe_desc_check, worlds per kind).  perturb != 0: the oracle steps a world
+    whose damping differs by that much (negative control: the comparison must notice)."""
     rng = np.random.RandomState(seed)
     B, T = 257, 3
     bad = refused = 0
@@ -106,12 +110,13 @@ def run(n_worlds, seed):
         vel = rng.uniform(-0.8, 0.8, (A, 2, B))
         goal = rng.randint(0, max(spec.n_landmarks, 1), B)
         hier = spec.kind == O.HIER_PURSUIT
+        ragged = hier or spec.kind == O.WORLD_COMM
         lf0 = rng.uniform(-1, 1, (A, 2, B)) if hier and spec.has_leader_force else None
-        acts = [rng.rand(sum(spec.act_dims), B) if hier else rng.dirichlet(np.ones(5), (A, B)).transpose(0, 2, 1)
+        acts = [rng.rand(sum(spec.act_dims), B) if ragged else rng.dirichlet(np.ones(5), (A, B)).transpose(0, 2, 1)
                 for _ in range(T)]
         noises = [rng.randn(A, 2, B) for _ in range(T)]
         has_noise = any(spec.u_noise)
-        bo = O.BatchedOracle(spec)
+        bo = O.BatchedOracle(dataclasses.replace(spec, damping=spec.damping + perturb) if perturb else spec)
         for flags in (0, 1):
             set_call_flags(flags)
             try:
@@ -132,9 +137,10 @@ def run(n_worlds, seed):
                         if not ok:
                             bad += 1
                             err = np.nanmax(np.abs(x - y), initial=0.0)
-                            print('MISMATCH world %d (%s A=%d L=%d) flags=%d step %d %s: max err %.3e nan %d/%d   spec=%r'
-                                  % (w, kind, A, spec.n_landmarks, flags, t, nm, err, np.isnan(x).sum(), np.isnan(y).sum(), spec),
-                                  flush=True)
+                            if not perturb:
+                                print('MISMATCH world %d (%s A=%d L=%d) flags=%d step %d %s: max err %.3e nan %d/%d   spec=%r'
+                                      % (w, kind, A, spec.n_landmarks, flags, t, nm, err, np.isnan(x).sum(), np.isnan(y).sum(), spec),
+                                      flush=True)
                             raise StopIteration
             except StopIteration:
                 pass
