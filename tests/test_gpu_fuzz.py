@@ -20,3 +20,51 @@ def test_random_worlds_match_the_oracle():
     bad, _, _ = mod.run(30, 1, perturb=1e-6)            # negative control: a 1e-6 change of the damping is noticed
     assert bad >= 50
     assert set(kinds) == {'tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'wcomm'} and min(kinds.values()) >= 20
+
+
+@pytest.mark.parametrize('mk', ['tag', 'spread', 'hier', 'wcomm'])
+def test_batch_size_edges(mk, golden_dir):
+    """B = 1, around the wavefront / workgroup / tile sizes and around the small-batch switch (MPE_SPLIT_MAX_ENVS), each in
+    a row stride ld > B whose padding must stay untouched: default kernel choice and tile kernel against the oracle
+    (f64, 2 steps), f32 default == f32 tile bit for bit."""
+    import numpy as np
+    from oracle import mpe_oracle as O
+    from tests.gpu_util import HipSim, dev, set_call_flags
+    spec = {'tag': O.simple_tag_spec, 'spread': O.simple_spread_spec, 'wcomm': O.simple_world_comm_spec,
+            'hier': lambda: O.hier_spec_from_golden(np.load(os.path.join(golden_dir, 'h_S1L2F2_3Targets_100observe.npz')))}[mk]()
+    A, E = spec.n_agents, spec.n_entities
+    bo = O.BatchedOracle(spec)
+    rng = np.random.RandomState(11)
+    for B in (1, 2, 31, 63, 64, 65, 127, 129, 255, 256, 257, 511, 513, 32767, 32768, 32769):
+        ld = B + 64 + (B % 7)
+        pos = rng.uniform(-0.5, 0.5, (E, 2, B))
+        vel = rng.uniform(-0.5, 0.5, (A, 2, B))
+        acts = [rng.rand(sum(spec.act_dims), B) for _ in range(2)]
+        outs = {}
+        for dtype in (torch.float64, torch.float32):
+            for flags in (0, 1):
+                set_call_flags(flags)
+                try:
+                    sim = HipSim(spec, B, dtype, ld=ld)
+                    sim.pos.fill_(5.0); sim.vel.fill_(5.0)
+                    sim.set_state(pos, vel)
+                    for a in acts:
+                        act = torch.full((sum(spec.act_dims), ld), float('nan'), dtype=dtype, device='cuda')
+                        act[:, :B] = dev(a, dtype)
+                        sim.env_step(act.view(A, 5, ld) if sim.spec.act_dims == [5] * A else act)
+                    torch.cuda.synchronize()
+                    outs[(dtype, flags)] = sim.host()
+                    assert (sim.pos[..., B:] == 5.0).all() and (sim.vel[..., B:] == 5.0).all(), (mk, B, flags)
+                    for t in (sim.obs, sim.rew, sim.info):
+                        assert torch.isnan(t[..., B:]).all(), (mk, B, flags)
+                finally:
+                    set_call_flags(0)
+        p, v = pos, vel
+        for a in acts:
+            p, v, obs, rew, info = bo.env_step(p, v, a)
+        want = (p, v, np.concatenate(obs, 0), rew)
+        for flags in (0, 1):
+            for x, y in zip(outs[(torch.float64, flags)], want):
+                assert np.nanmax(np.abs(x - np.asarray(y).reshape(x.shape)), initial=0.0) <= 1e-9, (mk, B, flags)
+        for x, y in zip(outs[(torch.float32, 0)], outs[(torch.float32, 1)]):
+            assert np.array_equal(x, y, equal_nan=True), (mk, B)
