@@ -54,13 +54,18 @@ def random_hier(rng):
 
 
 def random_spec(rng):
-    kind = rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier', 'wcomm'])
+    kind = rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier', 'wcomm', 'big'])
     if kind == 'hier':
         return random_hier(rng)
     if kind == 'tag':
         spec = O.simple_tag_spec(int(rng.randint(1, 7)), int(rng.randint(1, 5)), int(rng.randint(0, 6)))
     elif kind == 'spread':
         spec = O.simple_spread_spec(int(rng.randint(1, 7)), int(rng.randint(1, 7)))
+    elif kind == 'big':       # up to the library's limits (64 agents, 128 entities): several agent chunks per tile
+        A = int(rng.randint(20, 65))
+        L = int(rng.randint(0, 129 - A))
+        n_good = int(rng.randint(1, A))
+        spec = O.simple_tag_spec(A - n_good, n_good, L) if rng.rand() < 0.6 else O.simple_spread_spec(A, max(L, 1))
     elif kind == 'wcomm':     # simple_world_comm.py: tag physics, food, two forests, a speaking leader (agent 0)
         spec = O.simple_world_comm_spec(int(rng.randint(1, 6)), int(rng.randint(1, 4)), int(rng.randint(0, 3)),
                                         int(rng.randint(1, 4)), 2)
@@ -146,6 +151,24 @@ def run(n_worlds, seed, perturb=0.0):
                 pass
             finally:
                 set_call_flags(0)
+        # f32 (its own arithmetic and, in the tile kernel, its own pair-loop shape): ONE step from the same state; the
+        # continuous outputs within 1e-4 of the f64 oracle (observations only where they carry no visibility masks)
+        p1, v1, obs1, _, _ = bo.env_step(pos, vel, acts[0], noises[0] if has_noise else None,
+                                         goal=goal if spec.kind in O.GOAL_KINDS else None)
+        if not perturb and np.isfinite(p1).all():
+            sim = HipSim(spec, B, torch.float32)
+            sim.set_state(pos, vel, goal, lf0)
+            sim.env_step(dev(acts[0], torch.float32), dev(noises[0], torch.float32) if has_noise else None)
+            gp, gv, go, _, _ = sim.host()
+            checks = [('pos', gp, p1), ('vel', gv, v1)]
+            if not ragged:
+                checks.append(('obs', go, np.concatenate(obs1, 0)))
+            for nm, x, y in checks:
+                if not np.allclose(x, np.asarray(y).reshape(x.shape), rtol=1e-4, atol=1e-4):
+                    bad += 1
+                    print('F32 MISMATCH world %d (%s A=%d L=%d) %s: max err %.3e   spec=%r'
+                          % (w, kind, A, spec.n_landmarks, nm, np.nanmax(np.abs(x - np.asarray(y).reshape(x.shape))), spec), flush=True)
+                    break
         kernels[kind] = kernels.get(kind, 0) + 1
     return bad, refused, {str(k): v for k, v in kernels.items()}
 
