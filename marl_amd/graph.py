@@ -167,3 +167,65 @@ class CapturedTrainSteps(object):
         if self.env.info_callback is not None:
             w._gather_tick = w._tick
         return self.last
+
+
+class CapturedUpdates(object):
+    """The learners' updates -- ``for tr in trainers: tr.update(trainers, t)`` at a step where an update is due
+    (maddpg.py:161-196, experiments/simple_train.py:295-299) -- as ONE HIP-graph replay.
+
+    An update of one MADDPG learner is ~150 small launches (two 3-layer networks forward and backward, per-variable
+    clipping, Adam, polyak); for batches of 1 024 the GPU work is a few hundred microseconds and the host path ~3 ms per
+    learner, every 100 steps.  At small env batches that is most of the training loop (``tools/train_demo.py``).
+
+    Construct it at a step where the update is due and every buffer holds at least ``max_replay_buffer_len``
+    transitions: the constructor performs that update eagerly (it is the warm-up) and records the same calls;
+    ``replay()`` then performs one update of every trainer per call.  The batch indices are drawn outside the graph by
+    ``ReplayBuffer.make_index`` (they depend on the rings' fill level) into fixed index tensors; the Gumbel noise of the
+    sampled actions comes from torch's graph-aware generator.  Adam runs in its ``capturable`` form (step counters
+    on the device).  Returns every trainer's ``[q_loss, p_loss, mean(target_q), mean(rew), mean(target_q_next),
+    std(target_q)]`` as device scalars (overwritten by the next replay)."""
+
+    def __init__(self, trainers):
+        self.trainers = list(trainers)
+        t0 = self.trainers[0]
+        dev, bs = t0.device, t0.args.batch_size
+        for tr in self.trainers:
+            if len(tr.replay_buffer) < tr.max_replay_buffer_len:
+                raise RuntimeError('every replay buffer must hold max_replay_buffer_len transitions (maddpg.py:162)')
+            for opt in (tr.p_opt, tr.q_opt):
+                for g in opt.param_groups:
+                    g['capturable'] = True
+                for st in opt.state.values():          # states made by earlier eager steps keep their counter on the host
+                    if torch.is_tensor(st.get('step')):
+                        st['step'] = st['step'].to(device=dev, dtype=torch.float32)
+        self.index = [torch.zeros(bs, dtype=torch.int64, device=dev) for _ in self.trainers]
+        self._draw()
+        first = self._body()                           # the update that is due now; creates the optimizer states
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        checks = [tr.replay_buffer.check_index for tr in self.trainers]
+        try:
+            for tr in self.trainers:
+                tr.replay_buffer.check_index = False   # the range check reads the indices back on the host
+            with _hip.on_device(dev):
+                with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                    self.last = self._body()
+        finally:
+            for tr, c in zip(self.trainers, checks):
+                tr.replay_buffer.check_index = c
+        for outs, eager in zip(self.last, first):      # a capture computes nothing: `last` reports the eager update
+            for o, e in zip(outs, eager):
+                o.copy_(e)
+
+    def _draw(self):
+        for tr, idx in zip(self.trainers, self.index):
+            idx.copy_(tr.replay_buffer.make_index(idx.numel()))
+            tr.replay_sample_index = idx
+
+    def _body(self):
+        return [tr.update_from_index(self.trainers, idx) for tr, idx in zip(self.trainers, self.index)]
+
+    def replay(self):
+        self._draw()
+        self.graph.replay()
+        return self.last

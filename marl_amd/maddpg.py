@@ -247,7 +247,11 @@ class MADDPGAgentTrainer(object):
         if not t % 100 == 0:                                              # :164
             return None
         self.replay_sample_index = self.replay_buffer.make_index(self.args.batch_size)
-        index = self.replay_sample_index
+        return self.update_from_index(agents, self.replay_sample_index)
+
+    def update_from_index(self, agents, index):
+        """maddpg.py:166-196: everything of ``update`` behind its two gates, for the batch ``index`` (a device int64
+        tensor) -- the part that ``marl_amd.graph.CapturedUpdates`` records."""
         obs_n, obs_next_n, act_n = [], [], []
         for i in range(self.n):                                           # :173-177
             obs, act, rew, obs_next, done = agents[i].replay_buffer.sample_index(index)

@@ -96,3 +96,61 @@ def test_ring_wrap_inside_a_replay():
     assert res[0][1] == res[1][1] == [(512 * 2, 512 * 7)] * 4
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
+
+
+def test_captured_updates_equal_eager_updates(monkeypatch):
+    """marl_amd.graph.CapturedUpdates: the learners' updates of a due step as one HIP-graph replay.  With the batch indices
+    and the Gumbel noise made deterministic (both draw from generators whose streams differ between eager calls and a
+    replay), three rounds of updates leave the same networks, targets and packed actor weights as the eager
+    ``tr.update`` loop, up to Adam's capturable form keeping its step counter in f32 on the device."""
+    import marl_amd.maddpg as M
+    from marl_amd.graph import CapturedUpdates
+    from marl_amd.replay_buffer import ReplayBuffer
+
+    def soft_sample_fixed(flat, sizes, generator=None):                # u = 1/2 everywhere: a constant shift, no noise
+        return torch.cat([torch.softmax(p, dim=-1) for p in torch.split(flat, sizes, dim=-1)], dim=-1)
+    calls = {'n': 0}
+
+    def make_index_fixed(self, batch_size):
+        calls['n'] += 1
+        return (torch.arange(batch_size, device=self.device, dtype=torch.int64) * 37 + 11 * (calls['n'] % 4 + 1)) % self._len
+    monkeypatch.setattr(M, 'soft_sample', soft_sample_fixed)
+    monkeypatch.setattr(ReplayBuffer, 'make_index', make_index_fixed)
+
+    def build():
+        env, trainers = _setup(512)
+        obs_n = env.reset()
+        for _ in range(14):                                            # 14 x 512 transitions >= 256 x 25
+            obs_n = _iteration(env, trainers, obs_n)
+        return env, trainers
+    (_, ta), (_, tb) = build(), build()
+    calls['n'] = 0
+    outs_a = []
+    for t in (100, 200, 300):
+        for tr in ta:
+            tr.preupdate()
+        outs_a.append([tr.update(ta, t) for tr in ta])
+    calls['n'] = 0
+    cap = CapturedUpdates(tb)                                          # performs the first due update itself
+    outs_b = [[[x.clone() for x in o] for o in cap.last]]
+    for _ in range(2):
+        outs_b.append([[x.clone() for x in o] for o in cap.replay()])
+    torch.cuda.synchronize()
+    # Adam divides by sqrt(v): rounding-level differences of a gradient (the capturable form's f32 step counter, the order
+    # of a reduction) come back as ~1e-4 in a weight after three steps of lr = 1e-2, against steps of ~1e-2 each
+    init = _setup(512)[1]
+    for a, b, c in zip(ta, tb, init):
+        for net in ('p', 'q', 'target_p', 'target_q'):
+            for x, y, z in zip(*[[w.detach() for w in getattr(tr, net).parameters()] for tr in (a, b, c)]):
+                assert float((x - y).abs().max()) <= 2e-3, (a.name, net)
+                if net in ('p', 'q') and x.dim() == 2:
+                    assert float((x - z).abs().max()) >= 1e-2 and float((x - y).abs().max()) < 0.1 * float((x - z).abs().max())
+        assert float((a._packed - b._packed).abs().max()) <= 2e-3
+        assert torch.equal(a.replay_sample_index, b.replay_sample_index)
+    for ra, rb in zip(outs_a, outs_b):
+        for oa, ob in zip(ra, rb):
+            for x, y in zip(oa, ob):
+                assert torch.allclose(x, y, rtol=5e-2, atol=1e-3)
+    assert not torch.allclose(outs_b[0][0][0], outs_b[2][0][0])        # the replays really train (the loss moves)
+    with pytest.raises(RuntimeError):
+        CapturedUpdates(_setup(64)[1])                                 # empty buffers: no update is due (maddpg.py:162)

@@ -2,7 +2,8 @@
 step -> per-agent replay rings -> MADDPG updates every 100 steps.  Prints agent-steps/s with the learner in the
 loop (run on the GPU box from the repo root):
     python tools/train_demo.py [scenario] [num_envs] [steps] [eager]
-One episode (25 iterations) is one HIP-graph replay (marl_amd.graph.CapturedTrainSteps) unless `eager` is given."""
+One episode (25 iterations) is one HIP-graph replay (marl_amd.graph.CapturedTrainSteps) and the learners' updates
+another (CapturedUpdates) unless `eager` is given."""
 import os
 import sys
 import time
@@ -12,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marl_amd import make_env  # noqa: E402
-from marl_amd.graph import CapturedTrainSteps  # noqa: E402
+from marl_amd.graph import CapturedTrainSteps, CapturedUpdates  # noqa: E402
 from marl_amd.maddpg import MADDPGAgentTrainer, act_all  # noqa: E402
 from marl_amd.replay_buffer import add_all  # noqa: E402
 
@@ -41,6 +42,7 @@ def main():
     obs_n = iteration(obs_n)                            # the rings and the packed actor weights exist after this
     obs_n = env.reset()
     episode = None if eager else CapturedTrainSteps(env, trainers, EP)
+    updates = None
     for t in range(EP, steps + 100 + 1, EP):
         if t == 100 + EP:                               # 100 warm-up steps, incl. the first update
             torch.cuda.synchronize()
@@ -53,8 +55,15 @@ def main():
         obs_n = env.reset()
         for tr in trainers:
             tr.preupdate()
-        for tr in trainers:
-            out = tr.update(trainers, t)                # every 100 steps (maddpg.py:161-163), i.e. every 4th episode
+        due = t % 100 == 0 and all(len(tr.replay_buffer) >= tr.max_replay_buffer_len for tr in trainers)
+        if eager or not due:
+            for tr in trainers:
+                out = tr.update(trainers, t)            # every 100 steps (maddpg.py:161-163), i.e. every 4th episode
+        elif updates is None:
+            updates = CapturedUpdates(trainers)         # performs this step's update and records it
+            out = updates.last[-1]
+        else:
+            out = updates.replay()[-1]                  # all four learners' updates: one HIP-graph replay
         if out is not None:
             print('step %5d  q_loss %.4f  p_loss %.4f  mean reward %.3f' % (t, float(out[0]), float(out[1]), float(out[3])))
     torch.cuda.synchronize()
