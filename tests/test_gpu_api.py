@@ -685,3 +685,51 @@ def test_scripted_agents_match_reference(golden_dir, name, dtype, tol):
     o2 = env.step([k[j] for j in range(env.n)])[0]
     for a, b in zip(o1, o2):
         assert torch.equal(a, b)
+
+
+def test_scripted_speaking_leader_in_a_command_hierarchy():
+    """A scripted agent that speaks (core.py:126-127 with action.c): in S1L2F2_3Targets_100observe the first leader gets
+    its physical force AND its 7-entry command from a callback; the command pushes its followers (core.py:153-194) and
+    lands in state.c.  Against the oracle, which takes the callback's u as the force and reads the command from the
+    leader's comm rows."""
+    import marl_amd.scenarios as scenarios
+    from marl_amd.core import Action
+    from marl_amd.environment import MultiAgentEnv
+    B, T = 300, 6
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'h_S1L2F2_3Targets_100observe.npz'))
+    spec = O.hier_spec_from_golden(g)
+    scen = scenarios.load('S1L2F2_3Targets_100observe.py').Scenario(num_envs=B, dtype=torch.float64, seed=4)
+    world = scen.make_world()
+    lead = next(i for i, a in enumerate(world.agents) if not a.silent and not a.advsuperleader)
+    cmd = torch.tensor([0.1, 0.2, 0.05, 0.3, 0.15, 0.9, 0.4], dtype=torch.float64, device='cuda')   # argmax 5: "towards me"
+
+    def cb(agent, w):
+        a = Action()
+        a.u = 0.5 * torch.sign(w.landmarks[0].state.p_pos - agent.state.p_pos)
+        a.c = cmd.expand(w.num_envs, 7) * (1.0 + agent.state.p_pos[:, :1].abs())      # per-env scaling, same argmax
+        return a
+    world.agents[lead].action_callback = cb
+    env = MultiAgentEnv(world, scen.reset_world, scen.reward, scen.observation, scen.benchmark_data)
+    policy = [i for i in range(spec.n_agents) if i != lead]
+    assert env.n == spec.n_agents - 1 and [a._index for a in env.agents] == policy
+    env.reset()
+    bo = O.BatchedOracle(spec)
+    pos, vel = _np(world.pos), _np(world.vel)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+    for t in range(T):
+        action_n = [torch.rand(B, spec.act_dims[i], generator=gen, device='cuda', dtype=torch.float64) for i in policy]
+        u = 0.5 * np.sign(pos[spec.n_agents] - pos[lead])                       # landmark 0 = entity n_agents
+        c = _np(cmd)[:, None] * (1.0 + np.abs(pos[lead][:1]))
+        obs_n, rew_n, _, info_n = env.step(action_n)
+        act = np.zeros((sum(spec.act_dims), B))
+        for i, a in zip(policy, action_n):
+            act[offs[i]:offs[i + 1]] = _np(a).T
+        act[offs[lead] + 5:offs[lead + 1]] = c
+        pos, vel, obs, rew, info, lf = bo.env_step(pos, vel, act, return_lforce=True, scripted_u={lead: u})
+        np.testing.assert_allclose(_np(world.pos), pos, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(_np(world.lforce), lf, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(_np(torch.cat(obs_n, 1)).T, np.concatenate([obs[i] for i in policy], 0), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.stack([_np(r) for r in rew_n]), rew[policy], rtol=0, atol=1e-9)
+        assert np.array_equal(_np(world.agents[lead].state.c).T, c)
+    assert np.abs(lf).max() > 0                                                 # somebody was pushed by the scripted command
