@@ -258,6 +258,7 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     torch.cuda.synchronize()
 
     counts = {'resets': 0, 'stats_reads': 0, 'graph_replays': 0, 'eager_steps': 0}
+    pending = []        # the previous boundary's all-reduce, left running on RCCL's stream beside the next episode
 
     def run(segs, events=None, count=False):
         """events: list collecting (start, end, n_launches) HIP-event brackets around each run of consecutive
@@ -265,7 +266,11 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
         gap per step)."""
         for boundary, pos, length in segs:
             if boundary:
-                stats_total.add_(stats.read())      # deterministic reduce + one all-reduce / episode
+                # deterministic reduce + one all-reduce per episode; the collective runs beside the reset and the
+                # next episode's steps and is waited for at the next boundary (or at the end of the run)
+                if pending:
+                    stats_total.add_(EpisodeStats.finish(pending.pop()))
+                pending.append(stats.read_async())
                 stats.reset()
                 env.reset()
                 if count:
@@ -288,6 +293,8 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
                 events.append((e0, e1, length))
+        if pending:
+            stats_total.add_(EpisodeStats.finish(pending.pop()))
 
     use_dist = dist.is_initialized()
 

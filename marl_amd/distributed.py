@@ -60,5 +60,24 @@ class EpisodeStats(object):
         vec = self.world.read_stats()
         return all_reduce_stats(vec, self.group)
 
+    def read_async(self):
+        """Like ``read`` but does not make the current stream wait for the collective: returns ``(vec, work)``; the
+        all-reduce runs on RCCL's own stream beside whatever is enqueued next (the reset and the next episode's steps)
+        until ``finish`` is called.  ``work`` is None without a process group or with the gloo rehearsal backend, whose
+        host staging is synchronous."""
+        vec = self.world.read_stats()
+        if (dist.is_available() and dist.is_initialized() and vec.is_cuda
+                and dist.get_backend(self.group) != 'gloo'):
+            return vec, dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return all_reduce_stats(vec, self.group), None
+
+    @staticmethod
+    def finish(pending):
+        """Orders the current stream behind the collective of ``read_async`` and returns the reduced vector."""
+        vec, work = pending
+        if work is not None:
+            work.wait()
+        return vec
+
     def summary(self, steps_per_episode=25):
         return summarize_stats(self.read(), len(self.world.agents), steps_per_episode)
