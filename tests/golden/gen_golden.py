@@ -99,7 +99,7 @@ def build_hier_env(name, seed):
     return env, world
 
 
-def rollout_hier(name, seeds, T, init=None, actions='rand'):
+def rollout_hier(name, seeds, T, init=None, actions='rand', force_discrete=False):
     """Like rollout(); actions are ragged (5 physical + dim_c comm entries for non-silent agents,
     environment.py:161-168) and stored concatenated agent by agent; agent.leader_force recorded."""
     keys = ('pos0', 'vel0', 'obs0', 'lforce0', 'act', 'pos', 'vel', 'lforce', 'obs', 'rew', 'info')
@@ -131,6 +131,9 @@ def rollout_hier(name, seeds, T, init=None, actions='rand'):
                             e = np.exp(z - z.max())
                             v.append(e / e.sum())
                     parts.append(np.concatenate(v))
+            if force_discrete:      # environment.py:184-187 on a MultiDiscrete action: only action[0], the physical part
+                env.force_discrete_action = True
+                parts = [np.concatenate([np.round(p[:5] * 3) / 3, p[5:]]) for p in parts]     # coarse grid: ties
             obs_n, rew_n, done_n, info_n = env.step([p.copy() for p in parts])
             pos, vel = _state(world)
             ep['act'].append(np.concatenate(parts))
@@ -445,6 +448,9 @@ def rollout_comm(kind, seeds, T, init=None, c_noise=None):
             ep['cnoise'].append(cn)
             if crypto and t % 5 == 4:          # an all-zero message switches the reward terms off (:104,109,119)
                 parts[(t // 5) % 2] = np.zeros(act_dims[0])
+            if force_discrete:      # environment.py:184-187 on a MultiDiscrete action: only action[0], the physical part
+                env.force_discrete_action = True
+                parts = [np.concatenate([np.round(p[:5] * 3) / 3, p[5:]]) for p in parts]     # coarse grid: ties
             obs_n, rew_n, done_n, info_n = env.step([p.copy() for p in parts])
             pos, vel = _state(world)
             ep['act'].append(np.concatenate(parts))
@@ -608,6 +614,8 @@ def discrete_cases():
     save('g15_simple_spread_index_actions', **rollout('simple_spread', range(8), 25, init=dense_init, actions='index'))
     save('g16_simple_tag_force_discrete', **rollout('simple_tag', range(16), 25, actions='force'))
     save('g16_simple_push_force_discrete', **rollout('simple_push', range(8), 25, init=dense_init, actions='force'))
+    save('g16_h_S1L2F2_3Targets_100observe_force_discrete',
+         **rollout_hier('S1L2F2_3Targets_100observe', range(8), 25, init=dense_init, force_discrete=True))
 
 
 def hier_rest():

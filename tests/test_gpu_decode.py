@@ -190,3 +190,33 @@ def test_env_api_integer_actions_refused_for_speaking_agents():
     env.discrete_action_input = True
     with pytest.raises(AssertionError):                 # environment.py:208
         env.step([torch.zeros(8, dtype=torch.int64, device='cuda')] * 2)
+
+
+@pytest.mark.parametrize('flags', [0, 1], ids=['register_kernel', 'tile_kernel'])
+def test_force_discrete_on_multidiscrete_actions_matches_reference(golden_dir, flags):
+    """S1L2F2_3Targets_100observe with env.force_discrete_action: the decode pass rewrites the 5 physical rows of every
+    agent and leaves the leaders' 7 command rows alone; 25 free-running steps within 1e-9 of the reference (f64)."""
+    from tests.gpu_util import set_call_flags
+    g = _load(golden_dir, 'g16_h_S1L2F2_3Targets_100observe_force_discrete')
+    spec = O.hier_spec_from_golden(g)
+    S, T = g['act'].shape[:2]
+    set_call_flags(flags)
+    try:
+        sim = HipSim(spec, S, torch.float64)
+        sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'), lforce=golden_soa(g, 'lforce0'))
+        offs = np.concatenate([[0], np.cumsum(spec.act_dims)])
+        for t in range(T):
+            act = dev(np.ascontiguousarray(g['act'][:, t].T), torch.float64)
+            before = act.clone()
+            _decode(sim, 'force', act)
+            for i in range(spec.n_agents):
+                assert torch.equal(act[offs[i] + 5:offs[i + 1]], before[offs[i] + 5:offs[i + 1]])      # command rows
+                assert ((act[offs[i]:offs[i] + 5] == 1).sum(0) == 1).all() and (act[offs[i]:offs[i] + 5].sum(0) == 1).all()
+            sim.env_step(act)
+            pos, vel, obs, rew, info = sim.host()
+            np.testing.assert_allclose(pos, golden_soa(g, 'pos', t), rtol=0, atol=1e-9)
+            np.testing.assert_allclose(sim.lforce.cpu().numpy(), golden_soa(g, 'lforce', t), rtol=0, atol=1e-9)
+            np.testing.assert_allclose(obs, g['obs'][:, t].T, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(rew, golden_soa(g, 'rew', t), rtol=0, atol=1e-9)
+    finally:
+        set_call_flags(0)

@@ -630,3 +630,31 @@ def test_oracle_scripted_agents_bit_exact(golden_dir, name, monkeypatch):
             p, v = env.get_state()
             assert np.array_equal(p, g['pos'][s, t]) and np.array_equal(v, g['vel'][s, t]), (name, s, t)
             assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]) and np.array_equal(np.asarray(rew_n, float), g['rew'][s, t])
+
+
+def test_oracle_force_discrete_on_multidiscrete_actions_bit_exact(golden_dir):
+    """environment.py:161-168,184-187: with a MultiDiscrete action only action[0], the 5 physical entries, goes through the
+    argmax -> one-hot; the command entries keep their soft values (and still pick the leader's command by argmax)."""
+    g = _load(golden_dir, 'g16_h_S1L2F2_3Targets_100observe_force_discrete')
+    spec = O.hier_spec_from_golden(g)
+    S, T = g['act'].shape[:2]
+    bo = O.BatchedOracle(spec, force_discrete_action=True)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    for t in range(T):
+        pos, vel, obs, rew, info, lf = bo.env_step(pos, vel, g['act'][:, t].T, return_lforce=True)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), t
+        assert np.array_equal(lf, np.moveaxis(g['lforce'][:, t], 0, -1)), t
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), t
+        assert np.array_equal(rew, g['rew'][:, t].T), t
+    for s in range(3):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.force_discrete_action = True
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        for a, lf in zip(env.agents, g['lforce0'][s]):
+            a.leader_force = lf.copy()
+        for t in range(T):
+            obs_n, rew_n, _, _ = env.step([a.copy() for a in _split_actions(g, s, t)])
+            assert np.array_equal(env.get_state()[0], g['pos'][s, t]) and np.array_equal(np.concatenate(obs_n), g['obs'][s, t])
+    a = g['act'][:, :, :5]
+    assert ((a == a.max(-1, keepdims=True)).sum(-1) > 1).any()          # ties in a follower's physical entries
