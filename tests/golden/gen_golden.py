@@ -392,7 +392,50 @@ def rollout_scripted(name, seeds, T, init=None):
     return res
 
 
+def rollout_shared_done(seeds, T):
+    """environment.py:33,113-115 + :146-149: simple_spread with world.collaborative = True (upstream's simple_spread sets it,
+    this fork's copy does not: every agent then receives the SUM of the rewards) and a done_callback (an agent is done
+    once it is within 0.25 of some landmark).  Dense starts, so that both fire."""
+    keys = ('pos0', 'vel0', 'act', 'pos', 'vel', 'obs', 'rew', 'done')
+    out = {k: [] for k in keys}
+    for seed in seeds:
+        np.random.seed(seed)
+        S = SPREAD.Scenario()
+        world = S.make_world()
+        _shim(world)
+        world.collaborative = True
+
+        def done(agent, world):
+            return bool(min(np.sqrt(np.sum(np.square(agent.state.p_pos - l.state.p_pos))) for l in world.landmarks) < 0.25)
+        env = MultiAgentEnv(world, S.reset_world, S.reward, S.observation, S.benchmark_data, done_callback=done)
+        assert env.shared_reward
+        A = len(world.agents)
+        env.reset()
+        dense_init(world, np.random.RandomState(10_000 + seed))
+        pos0, vel0 = _state(world)
+        arng = np.random.RandomState(20_000 + seed)
+        ep = {k: [] for k in ('act', 'pos', 'vel', 'obs', 'rew', 'done')}
+        for t in range(T):
+            act = arng.rand(A, 5)
+            obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in range(A)])
+            pos, vel = _state(world)
+            ep['act'].append(act)
+            ep['pos'].append(pos.copy())
+            ep['vel'].append(vel.copy())
+            ep['obs'].append(np.concatenate(obs_n))
+            ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
+            ep['done'].append(np.asarray(done_n, dtype=bool))
+        out['pos0'].append(pos0)
+        out['vel0'].append(vel0)
+        for k in ep:
+            out[k].append(np.stack(ep[k]))
+    res = {k: np.stack(v) for k, v in out.items()}
+    res['seeds'] = np.asarray(list(seeds))
+    return res
+
+
 def scripted_cases():
+    save('g17_simple_spread_shared_reward_done', **rollout_shared_done(range(16), 25))
     for name in SCRIPTED:
         save(name, **rollout_scripted(name, range(16), 25))
         save(name + '_dense', **rollout_scripted(name, range(16), 25, init=dense_init))

@@ -733,3 +733,41 @@ def test_scripted_speaking_leader_in_a_command_hierarchy():
         np.testing.assert_allclose(np.stack([_np(r) for r in rew_n]), rew[policy], rtol=0, atol=1e-9)
         assert np.array_equal(_np(world.agents[lead].state.c).T, c)
     assert np.abs(lf).max() > 0                                                 # somebody was pushed by the scripted command
+
+
+@pytest.mark.parametrize('with_done', [True, False], ids=['callback_path', 'fused_path'])
+def test_shared_reward_and_done_callback_match_reference(golden_dir, with_done):
+    """environment.py:33,113-115 (world.collaborative: every agent receives the sum of the rewards) and :146-149 (a
+    done_callback), against a fixture generated from the reference with both set on simple_spread.  A done_callback takes
+    the env off the fused launch (World.step + the callbacks, like environment.py:105-110); without it the same rewards
+    come from the fused path."""
+    import marl_amd.scenarios as scenarios
+    from marl_amd.environment import MultiAgentEnv
+    from tests.gpu_util import dev, golden_soa
+    g = np.load(os.path.join(golden_dir, 'g17_simple_spread_shared_reward_done.npz'))
+    S, T = g['act'].shape[:2]
+    scen = scenarios.load('simple_spread.py').Scenario(num_envs=S, dtype=torch.float64, seed=1)
+    world = scen.make_world()
+    world.collaborative = True
+
+    def done(agent, world):
+        d = torch.stack([(agent.state.p_pos - l.state.p_pos).pow(2).sum(1).sqrt() for l in world.landmarks]).min(0).values
+        return d < 0.25
+    env = MultiAgentEnv(world, scen.reset_world, scen.reward, scen.observation, scen.benchmark_data,
+                        done_callback=done if with_done else None)
+    assert env.shared_reward and env._fused == (not with_done)
+    env.reset()
+    world.pos.copy_(dev(golden_soa(g, 'pos0'), torch.float64))
+    world.vel.copy_(dev(golden_soa(g, 'vel0'), torch.float64))
+    world.mark_dirty()
+    for t in range(T):
+        obs_n, rew_n, done_n, info_n = env.step([dev(g['act'][:, t, i], torch.float64) for i in range(env.n)])
+        np.testing.assert_allclose(_np(world.pos), golden_soa(g, 'pos', t), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(_np(torch.cat(obs_n, 1)), g['obs'][:, t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(_np(torch.stack(rew_n, 1)), g['rew'][:, t], rtol=0, atol=1e-9)
+        assert rew_n[0] is rew_n[1] is rew_n[2]                              # [reward] * n (environment.py:115)
+        if with_done:
+            assert np.array_equal(torch.stack(done_n, 1).cpu().numpy(), g['done'][:, t])
+        else:
+            assert not any(d.any() for d in done_n)
+    assert g['done'].any() and not g['done'].all()
