@@ -163,8 +163,18 @@ def run(n_worlds, seed, perturb=0.0):
             checks = [('pos', gp, p1), ('vel', gv, v1)]
             if not ragged:
                 checks.append(('obs', go, np.concatenate(obs1, 0)))
+            # 1e-4 relative to the scale of the step: in a crowd of 100 overlapping entities an agent's force is a sum
+            # of dozens of contact terms of either sign, and f32 rounds each of them relative to ITS size, not to the
+            # net velocity that is left (the f64 leg above holds 1e-9 on the same worlds)
+            scale = max(1.0, float(np.abs(v1).max()))
+            # ... and no worse than a few times what the same operations in numpy float32 lose on this world (the speed
+            # clamp turns a cancellation error of the force into an error of the direction, whatever |v| is)
+            p32, v32, _, _, _ = O.BatchedOracle(spec, np.float32).env_step(
+                pos, vel, acts[0], noises[0] if has_noise else None, goal=goal if spec.kind in O.GOAL_KINDS else None)
+            slack = 8.0 * max(float(np.nanmax(np.abs(np.asarray(v32, np.float64) - v1))),
+                              float(np.nanmax(np.abs(np.asarray(p32, np.float64) - p1))))
             for nm, x, y in checks:
-                if not np.allclose(x, np.asarray(y).reshape(x.shape), rtol=1e-4, atol=1e-4):
+                if not np.allclose(x, np.asarray(y).reshape(x.shape), rtol=1e-4, atol=1e-4 * scale + slack):
                     bad += 1
                     print('F32 MISMATCH world %d (%s A=%d L=%d) %s: max err %.3e   spec=%r'
                           % (w, kind, A, spec.n_landmarks, nm, np.nanmax(np.abs(x - np.asarray(y).reshape(x.shape))), spec), flush=True)
