@@ -45,7 +45,11 @@
  *     STATE (hardware rsq / exp / log, ~1 ulp each).  Over a free-running episode f32 trajectories drift apart
  *     like any chaotic contact dynamics in single precision, and the discrete outputs (rewards of +-10, contact
  *     counts, visibility masks, the order of equidistant targets) can differ from the float64 reference on an
- *     env that sits within ~1e-5 of a strict `<` threshold.
+ *     env that sits within ~1e-5 of a strict `<` threshold.  "Relative" means relative to the terms summed: an agent in
+ *     contact with dozens of entities at once (100-entity worlds packed into a unit square) has a net force far smaller
+ *     than its contact terms, and single precision rounds each term to 2^-24 of ITS size -- the same loss numpy float32
+ *     shows on those worlds (tools/fuzz_parity.py measures the kernels against it); the BASELINE configurations are
+ *     nowhere near that regime.
  */
 #ifndef MPE_HIP_H
 #define MPE_HIP_H
