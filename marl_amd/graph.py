@@ -198,6 +198,10 @@ class CapturedUpdates(object):
                 for st in opt.state.values():          # states made by earlier eager steps keep their counter on the host
                     if torch.is_tensor(st.get('step')):
                         st['step'] = st['step'].to(device=dev, dtype=torch.float32)
+        from .maddpg import pack_actor
+        for tr in self.trainers:                       # the recorded update refills the packed actor weights in place:
+            if tr._packed is None:                     # they must exist before the capture, or later acting steps
+                tr._packed = pack_actor(tr.p)          # would read weights no replay ever refreshes
         self.index = [torch.zeros(bs, dtype=torch.int64, device=dev) for _ in self.trainers]
         self._draw()
         first = self._body()                           # the update that is due now; creates the optimizer states
