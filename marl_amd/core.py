@@ -74,9 +74,8 @@ class AgentState(EntityState):
         w = self._e._world
         r = w.comm[self._e._index]
         r.copy_(torch.as_tensor(value, dtype=r.dtype, device=r.device).expand(r.shape[1], r.shape[0]).t())
-        w.mark_dirty()      # observations of the speaking scenarios read other.state.c
-        if self._e.silent:  # the next step sets it back to zeros (core.py:226-227): World._clean_silent_comm
-            w._silent_comm_dirty = True
+        w.mark_comm_dirty()     # observations of the speaking scenarios read other.state.c; a silent agent's rows go
+                                # back to zeros with the next step (core.py:226-227): World._clean_silent_comm
 
 
 class Action(object):
@@ -343,6 +342,13 @@ class World(object):
     def mark_dirty(self):
         """Call after writing world.pos / world.vel directly (setters on entity.state do it)."""
         self._tick += 1
+
+    def mark_comm_dirty(self):
+        """Call after writing ``world.comm`` directly (``agent.state.c = ...`` does it): cached observations are
+        dropped, and the rows of silent agents are zeroed again in front of the next step, which no longer rewrites
+        them itself (FLAG_SILENT_COMM_ZERO; core.py:226-227 leaves a silent agent's state.c at zeros)."""
+        self._tick += 1
+        self._silent_comm_dirty = True
 
     def _alloc_outputs(self):
         d = self.descriptor()
