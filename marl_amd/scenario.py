@@ -37,7 +37,10 @@ class HipScenario(BaseScenario):
         from . import _hip
         d = world.descriptor()
         fn = getattr(_hip.lib, 'mpe_reset_' + _hip.suffix(world.dtype))
-        b = _hip.Buffers(pos=world.pos, vel=world.vel, comm=world.comm if world.comm.numel() else None,
+        # agent.state.c = zeros(dim_c) (simple_tag.py:51): the rows of silent agents hold zeros already (World.allocate,
+        # World._clean_silent_comm), so only a world in which somebody speaks has anything to clear
+        world._clean_silent_comm()
+        b = _hip.Buffers(pos=world.pos, vel=world.vel, comm=world._comm_arg,
                          goal=world.goal if world.hip_kind in _hip.GOAL_KINDS else None)
         with _hip.on_device(world.device):
             _hip.check(fn(d, world.num_envs, world.ld, world.seed, world.episode, world.env_id0,
