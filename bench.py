@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: typed without a launcher, bench.py times the CPU baseline and then starts the N ranks
+itself as fresh child processes through torch.distributed.run (`self_launch`); the parent never touches a GPU.
+
 One "step" = one MultiAgentEnv.step() over the rank's whole batch (action decode + World.step +
 observation + reward + benchmark info for all agents, one fused HIP launch).  Episodes are 25 steps
 (BASELINE.md); at every episode boundary the loop reads the episode statistics (deterministic on-device
@@ -16,7 +19,8 @@ The runs of consecutive steps between boundaries are replayed as HIP graphs (mar
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, fused env-step
 kernel, HIP-event brackets around the launches inside the timed region), `cpu_baseline` (the oracle's serial
-numpy loop on one host core and on all of the box's cores, rank 0 at N=1 only) and, at N=1 with the default
+numpy loop on one host core and on all of the box's cores; timed once, by rank 0 or by the self-launching parent,
+before that process touches a GPU) and, at N=1 with the default
 workload, `other_configs`: short runs of the other single-GPU BASELINE configs, each with its own roofline.
 """
 import argparse
@@ -84,12 +88,14 @@ def algorithmic_elems(env, with_info=True):
     return sum(w.act_dims) + pos_rd + 2 * moving + 4 * moving + obs + A + A * info_w + extra
 
 
-def measured_traffic(workload):
-    """HBM bytes per fused launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    tools/summarize_pmc.py); None when no pass was recorded for this workload."""
+def measured_pmc(workload):
+    """The fused launch's entry in the committed rocprofv3 PMC summary of this workload (tools/profile.sh ->
+    tools/summarize_pmc.py): `traffic_bytes` = HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950
+    correction) and the `sq` block's `valu_util` (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles)) and
+    `wave_wait_frac` (SQ_WAIT_ANY / SQ_WAVE_CYCLES); {} when no pass was recorded for this workload."""
     path = os.path.join(ROOT, 'profiles', 'pmc_%s.json' % workload)
     if not os.path.exists(path):
-        return None
+        return {}
     ks = json.load(open(path))['kernels']
 
     def is_fused(name):      # template tails: small/hier <..., DO_STEP, DO_OBS>, tile <..., DO_STEP, DO_OBS, HIER[, KIND]>
@@ -98,7 +104,7 @@ def measured_traffic(workload):
             return args[3:5] == ['true', 'true']
         return args[-2:] == ['true', 'true']
     fused = [v for k, v in ks.items() if 'mpe::' in k and is_fused(k)]
-    return fused[0]['traffic_bytes'] if fused else None
+    return fused[0] if fused else {}
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -329,6 +335,8 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     else:
         kern_ms = kern_med = elapsed * 1e3 / steps
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    # committed counter passes of exactly this workload at its own batch size (not re-collected by this run)
+    pmc = measured_pmc(name) if B == envs_per_gpu else {}
     out = {
         'metric': 'agent-steps/sec (whole node) for batched simple_tag' if scenario == 'simple_tag' and not kwargs
                   else 'agent-steps/sec (whole node), %s' % name,
@@ -349,7 +357,10 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
                    'parallelism': 'env-sharded dp%d' % world_size, 'backend': backend if use_dist else None},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': measured_traffic(name) if B == envs_per_gpu else None,
+                     'traffic': pmc.get('traffic_bytes'),
+                     'valu_util': pmc.get('sq', {}).get('valu_util'),
+                     'wave_wait_frac': pmc.get('sq', {}).get('wave_wait_frac'),
+                     'counters_from': 'profiles/pmc_%s.json' % name if pmc else None,
                      'kernel': 'mpe env_step (fused)', 'algorithmic_bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': elems * esize,
                      'avg_launch_ms': kern_ms, 'median_launch_ms': kern_med,
@@ -362,6 +373,48 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     del graphs, env, pool, stats
     torch.cuda.empty_cache()
     return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: time the CPU baseline here, then start the N
+    ranks as FRESH child processes (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>`, one rank per GPU over RCCL), relay rank 0's JSON line with `cpu_baseline` merged in, and return the
+    children's exit status.  This process makes no GPU call at any point (nothing is exec'ed after GPU initialisation,
+    and the forked CPU workers inherit no GPU state)."""
+    import socket
+    import subprocess
+    if args.backend == 'nccl' and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise HIP
+        print('bench.py: --gpus %d with backend nccl (RCCL) needs one GPU per rank; %d visible'
+              % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    cpu = None if args.no_cpu_baseline else cpu_baseline(args.cpu_baseline_seconds)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    if not args.no_cpu_baseline:
+        cmd.append('--no-cpu-baseline')
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)     # stderr passes through
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{')]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith('{'):
+            print(ln, file=sys.stderr)
+    if child.returncode != 0:
+        print('bench.py: the %d-rank child job ended with status %d' % (args.gpus, child.returncode), file=sys.stderr)
+        return child.returncode if 0 < child.returncode < 256 else 1
+    if len(lines) != 1:
+        print('bench.py: expected one JSON line from rank 0, got %d' % len(lines), file=sys.stderr)
+        return 1
+    out = json.loads(lines[0])
+    out['config']['launched_by'] = 'bench.py (fresh child ranks via torch.distributed.run)'
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
+    print(json.dumps(out))
+    return 0
 
 
 def main():
@@ -386,14 +439,16 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world_size = int(os.environ.get('WORLD_SIZE', 1))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-        args.gpus = world_size
+    if 'RANK' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher and never touches a GPU
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    args.gpus = world_size            # under a launcher the launcher's rank count is the truth
 
     cpu = None
-    if world_size == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_baseline_seconds)       # forks workers: before anything touches the GPU
+    if rank == 0 and not args.no_cpu_baseline:
+        # forks workers: before anything in this process touches the GPU.  Under a launcher with N > 1 the other
+        # ranks wait for rank 0 inside init_process_group meanwhile (its default timeout is minutes, this is seconds).
+        cpu = cpu_baseline(args.cpu_baseline_seconds)
 
     dev_index = local_rank if args.backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)

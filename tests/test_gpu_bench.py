@@ -64,6 +64,10 @@ def test_driver_command_line_has_an_episode_boundary_and_the_other_configs():
     assert cfg['resets_in_timed_region'] == 1 and cfg['stats_reads_in_timed_region'] == 1
     _check_roofline(d['roofline'], 504)
     assert d['roofline']['frac'] > 0.5
+    # north_star: "HBM GB/s and VALU utilisation from rocprof": the committed counter passes ride in the line
+    for r in [d['roofline']] + [o['roofline'] for o in d['other_configs'].values()]:
+        assert r['counters_from'].startswith('profiles/pmc_') and 0 < r['valu_util'] < 1 and 0 < r['wave_wait_frac'] < 1
+        assert 0.8 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 1.2
     oc = d['other_configs']
     assert set(oc) == {'simple_spread_64k_f64', 'scaled_tag_256k_f32', 'simple_tag_1M_f64'}
     _check_roofline(oc['simple_spread_64k_f64']['roofline'], 912)

@@ -82,3 +82,36 @@ def test_single_rank_under_torchrun_runs_the_rccl_path():
     plain = _single(30_011)
     assert plain['config']['backend'] is None
     assert one['episode_stats_vector'] == plain['episode_stats_vector']
+
+
+def test_bench_gpus_2_as_typed_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher (the driver's plain command form): the parent times the CPU
+    baseline without touching a GPU, starts the two ranks as fresh child processes, and prints ONE JSON line with
+    `n_gpus == 2`, `cpu_baseline`, and the statistics of the unsharded run.  (gloo: the two ranks share the one GPU.)"""
+    per_rank = 50_000
+    common = [a for a in COMMON if a != '--no-cpu-baseline'] + ['--cpu-baseline-seconds', '2']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                          '--envs', str(per_rank)] + common, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    two = _json(out)
+    assert two['n_gpus'] == 2 and two['config']['backend'] == 'gloo' and two['config']['stats_allreduce'] == 'per episode'
+    assert two['config']['parallelism'] == 'env-sharded dp2' and 'launched_by' in two['config']
+    c = two['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 1000 and c['all_cores']['value'] > 1000
+    whole = _single(2 * per_rank)
+    a, b = np.array(whole['episode_stats_vector']), np.array(two['episode_stats_vector'])
+    n = whole['config']['agents']
+    assert a[2 * n + 1] == b[2 * n + 1] == 2 * per_rank * 50
+    np.testing.assert_allclose(b, a, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(a[n:], b[n:])
+
+
+def test_bench_gpus_n_without_enough_gpus_fails_with_a_message_not_a_traceback():
+    """backend nccl needs one GPU per rank; on the one-GPU box `--gpus 2` must end non-zero before any child starts."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode == 2 and 'one GPU per rank' in out.stderr and 'Traceback' not in out.stderr
