@@ -85,7 +85,9 @@ def algorithmic_elems(env, with_info=True):
     extra = (2 * A if w.lforce is not None else 0) + w.dim_c * sum(1 for a in w.agents if not a.silent)
     moving = sum(1 for a in w.agents if a.movable)           # only movable agents have / update a velocity
     pos_rd = 2 * E if moving else 0                          # simple_crypto: nobody moves, nothing looks at positions
-    return sum(w.act_dims) + pos_rd + 2 * moving + 4 * moving + obs + A + A * info_w + extra
+    # u_noise normals supplied as a tensor are 2A more rows to read; drawn inside the kernel they are no traffic at all
+    noise_rd = 2 * A if (w.host_noise or w.noise is not None) and any(a.u_noise for a in w.agents) else 0
+    return sum(w.act_dims) + pos_rd + 2 * moving + 4 * moving + obs + A + A * info_w + extra + noise_rd
 
 
 def measured_pmc(workload):
@@ -188,7 +190,7 @@ def plan_segments(pos0, nsteps):
 
 
 def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend, use_graph=True, use_events=True,
-                 actions='random'):
+                 actions='random', u_noise=0.0, host_noise=False):
     from marl_amd import make_env, _hip
     from marl_amd.distributed import EpisodeStats, shard_range, summarize_stats
     from marl_amd.graph import CapturedSteps
@@ -200,6 +202,14 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
     has_info = scenario not in ('simple', 'simple_push', 'simple_speaker_listener', 'simple_reference')
     env = make_env(scenario, benchmark=has_info, num_envs=B, device=device, dtype=dtype, seed=0, **kwargs)
     env.world.env_id0 = env_id0
+    if u_noise:
+        # core.py:147-148: every agent's force gets u_noise * N(0, 1) per step.  The normals are drawn inside the step
+        # kernel, keyed by (seed, global env id, step, agent) -- or, with --host-noise, by torch's generator into a
+        # [A, 2, B] buffer per step (the round-2 path: one more launch, 4A more rows of traffic)
+        for a in env.world.agents:
+            a.u_noise = float(u_noise)
+        env.world.host_noise = bool(host_noise)
+        env.world.invalidate_descriptor()
     if os.environ.get('MPE_FLAGS'):           # tuning aid: kernel selection flags (include/mpe_hip.h, MPE_FLAG_*)
         env.world.set_flags(int(os.environ['MPE_FLAGS']))
     n = env.n
@@ -353,6 +363,9 @@ def run_workload(name, steps, warmup, B, device, rank, world_size, dist, backend
                    'graph_replays': counts['graph_replays'], 'eager_steps': counts['eager_steps'],
                    'graph_capture_error': graph_error,
                    'benchmark_info': has_info,
+                   'u_noise': u_noise or None,
+                   'noise_source': (None if not u_noise else 'torch generator, [A,2,B] buffer per step' if host_noise
+                                    else 'in-kernel Philox4x32-10 + Box-Muller keyed by global env id'),
                    'stats_allreduce': 'per episode' if use_dist else 'per episode (single rank: local reduce)',
                    'parallelism': 'env-sharded dp%d' % world_size, 'backend': backend if use_dist else None},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -432,6 +445,8 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configs')
     ap.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (roofline from wall time)')
     ap.add_argument('--no-graph', action='store_true', help='one host call per step instead of HIP-graph replays')
+    ap.add_argument('--u-noise', type=float, default=0.0, help='agent.u_noise of every agent (core.py:147); default none')
+    ap.add_argument('--host-noise', action='store_true', help='draw u_noise with torch\'s generator instead of in the kernel')
     ap.add_argument('--actions', default='random', choices=['random', 'by-env-id'],
                     help='by-env-id: the action of an env depends on its global id only (sharding-invariant runs)')
     args = ap.parse_args()
@@ -465,11 +480,13 @@ def main():
             dist.init_process_group('gloo')
 
     out = run_workload(args.workload, args.steps, args.warmup, args.envs, device, rank, world_size, dist, args.backend,
-                       use_graph=not args.no_graph, use_events=not args.no_events, actions=args.actions)
+                       use_graph=not args.no_graph, use_events=not args.no_events, actions=args.actions,
+                       u_noise=args.u_noise, host_noise=args.host_noise)
     if rank == 0:
         if cpu is not None:
             out['cpu_baseline'] = cpu
-        if (world_size == 1 and args.workload == 'simple_tag_1M_f32' and not args.envs and not args.no_other_configs):
+        if (world_size == 1 and args.workload == 'simple_tag_1M_f32' and not args.envs and not args.no_other_configs
+                and not args.u_noise):
             out['other_configs'] = {}
             for name, st, wu in OTHER_CONFIGS:
                 r = run_workload(name, st, wu, 0, device, 0, 1, dist, args.backend, use_graph=not args.no_graph,

@@ -14,7 +14,8 @@
  *   - Plain C, plain pointers and sizes.  All array arguments (the members of mpe_buffers, `mask`,
  *     the stats vectors) are DEVICE pointers; mpe_scenario_desc and mpe_buffers themselves live in
  *     host memory and are read during the call only.  The library allocates nothing, keeps no state that changes results (the only
- *     process-wide data is a per-device record of which kernels already had their dynamic-LDS limit raised),
+ *     process-wide data are a per-device record of which kernels already had their dynamic-LDS limit raised and, for
+ *     mpe_env_step_stats_static alone, the per-device address of its built-in scratch array and that array's contents),
  *     never synchronises: every call only enqueues kernels on `stream` (a hipStream_t passed as void*; NULL =
  *     default stream) of the CURRENT device, which must be the device that owns the buffers.  Safe to call
  *     concurrently from several threads / processes on different devices.
@@ -25,7 +26,8 @@
  *         vel  [A][2][ld]    landmarks never move in the supported scenarios
  *         act  [act_total][ld]  soft one-hot Discrete(5) action per agent (environment.py:188-190),
  *                            [A][5][ld] when every agent is silent; see mpe_buffers
- *         noise[A][2][ld]    standard normals for u_noise (core.py:147); may be NULL
+ *         noise[A][2][ld]    standard normals for u_noise (core.py:147); may be NULL (then none, or with
+ *                            MPE_FLAG_DEVICE_NOISE drawn in the kernel)
  *         comm [A][dim_c][ld]  agent.state.c, written as zeros (all agents silent, core.py:226-227);
  *                              may be NULL (then not written)
  *         obs  [obs_total][ld]  agent i owns rows [obs_row0(i), obs_row0(i)+obs_dim(i))
@@ -60,7 +62,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 9
+#define MPE_ABI_VERSION 10
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -110,7 +112,16 @@ extern "C" {
                                     rewriting agent.state.c = zeros(dim_c) (core.py:226-227) every time.  Same state
                                     afterwards, 5-10 % fewer rows written in the hierarchy worlds.  Without the flag
                                     every comm row is written by every step, whatever it held                          */
-#define MPE_FLAG_ALL 15u
+#define MPE_FLAG_DEVICE_NOISE 16u /* u_noise / c_noise normals (core.py:147-148,229) that the caller does not supply (noise /
+                                    cnoise NULL) are drawn inside the step kernels: Philox4x32-10, counter (global env id
+                                    lo, hi, step, 0x40000000 | agent) for an agent's two u_noise normals and (.., 0x60000000
+                                    | agent << 8 | j) for its c_noise components 2j, 2j + 1, key = noise_seed, Box-Muller;
+                                    global env id = env_id0 + index, step = noise_step (+ *noise_step_dev).  A draw depends
+                                    on (seed, env, step, agent, component) only: not on B, the sharding or the kernel form.
+                                    Without the flag an agent whose normals are not supplied gets no noise (as before).
+                                    f64: restated bit for bit by oracle/mpe_oracle.py:device_normals; f32: same Philox
+                                    words, hardware log / sin / cos, within ~1e-6 of the f64 normal                  */
+#define MPE_FLAG_ALL 31u
 #define MPE_SPLIT_MAX_ENVS 32768
 
 /*
@@ -183,7 +194,7 @@ typedef struct mpe_scenario_desc {
  */
 typedef struct mpe_buffers {
   const void *act;
-  const void *noise; /* [A][2][ld] standard normals for u_noise, or NULL */
+  const void *noise; /* [A][2][ld] standard normals for u_noise, or NULL (see MPE_FLAG_DEVICE_NOISE) */
   void *pos;         /* [E][2][ld] */
   void *vel;         /* [A][2][ld] */
   void *comm;        /* [A][dim_c][ld] agent.state.c, or NULL (then not written) */
@@ -194,14 +205,22 @@ typedef struct mpe_buffers {
   void *info;        /* [A][info_w][ld] */
   double *stats;     /* [mpe_stats_rows][mpe_stats_width] or NULL */
   const void *cnoise; /* [A][dim_c][ld] standard normals for c_noise (core.py:229): agent.state.c = action.c +
-                         c_noise * cnoise for a speaking agent with a c_noise; NULL = no comm noise */
+                         c_noise * cnoise for a speaking agent with a c_noise; NULL = no comm noise, or with
+                         MPE_FLAG_DEVICE_NOISE drawn in the kernel */
   uint32_t flags;     /* MPE_FLAG_* bits; unknown bits -> MPE_ERR_ARG */
+  /* MPE_FLAG_DEVICE_NOISE only (ignored without it) */
+  uint32_t noise_step;             /* step counter of this call: the caller bumps it by one per step */
+  uint64_t noise_seed;             /* Philox key */
+  uint64_t env_id0;                /* global id of env 0 of this call (shards of one batch: their offset) */
+  const uint32_t *noise_step_dev;  /* DEVICE word added to noise_step when not NULL: a step recorded in a HIP graph bakes
+                                      noise_step, so the part that moves from replay to replay lives in memory */
 } mpe_buffers;
 
 int mpe_abi_version(void);
 const char *mpe_strerror(int code);
 /* sizeof(mpe_scenario_desc) as compiled into the library (bindings check their struct layout). */
 int64_t mpe_desc_sizeof(void);
+int64_t mpe_buffers_sizeof(void);
 
 /* Validates a descriptor (counts, positive masses/margin, landmarks immovable). */
 int mpe_desc_check(const mpe_scenario_desc *desc);
@@ -307,7 +326,7 @@ int mpe_scripted_action_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld
                             double cap, const void *pos, void *act_out, void *point_out, void *stream);
 
 /*
- * The two non-default decodes of MultiAgentEnv._set_action (multiagent/environment.py:176-187), applied to the SoA
+ * The non-default decodes of MultiAgentEnv._set_action (multiagent/environment.py:176-192), applied to the SoA
  * action rows `act` ([mpe_act_total][ld], same layout as mpe_buffers.act) before a step call, which always runs the
  * default decode (:188-190).  One launch for all agents; agents that are not movable have no physical entries and
  * are skipped (:174).
@@ -320,7 +339,19 @@ int mpe_scripted_action_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld
  *   mpe_action_force_discrete  env.force_discrete_action, i.e. world.discrete_action (:33,184-187): the physical 5
  *                          entries of every movable agent become one_hot(np.argmax(.)) in place (first maximum; a
  *                          NaN wins); comm entries are left as they are.
+ *   mpe_action_from_force  env.discrete_action_space == False (:191-192; marked "NEVER do here" by the fork, but a live
+ *                          switch): the action of a movable agent IS the force command, agent.action.u = action[0], a
+ *                          2-vector, times the sensitivity.  u is [n_agents][2][ld_u]; the agent's 5 rows become
+ *                          (0, u_x, 0, u_y, 0), whose default decode returns u bit for bit.  force_discrete != 0: the
+ *                          argmax -> one-hot of :184-187 runs first, on the 2-vector (first maximum, a NaN wins).  A
+ *                          world with a movable agent that also speaks is refused (MPE_ERR_UNSUPPORTED): there the
+ *                          reference takes the first 5 entries of the MultiDiscrete action as u and fails in
+ *                          integrate_state (core.py:216, 2-vector += 5-vector).
  */
+int mpe_action_from_force_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int64_t ld_u, const void *u,
+                              int force_discrete, void *act, void *stream);
+int mpe_action_from_force_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int64_t ld_u, const void *u,
+                              int force_discrete, void *act, void *stream);
 int mpe_action_from_index_f32(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int64_t ld_idx,
                               const int32_t *idx, void *act, void *stream);
 int mpe_action_from_index_f64(const mpe_scenario_desc *desc, int64_t B, int64_t ld, int64_t ld_idx,
@@ -368,8 +399,9 @@ int mpe_replay_add_multi_f64(int n_jobs, const mpe_replay_job *jobs, int64_t n, 
  * (jobs[i].next_idx + *cursors[i]) % capacity (cursors[i] may be NULL = 0; cursors itself is a host array of n_jobs
  * device pointers, read during the call).  No counterpart in the reference: a launch recorded in a HIP graph bakes its
  * arguments, so a replayed training loop (act -> step -> store, experiments/simple_train.py:257-300) keeps the words that
- * change from replay to replay in memory.  Buffers the one-launch kernel does not cover (records wider than 63 f32 / 31 f64
- * columns, fewer than 256 transitions) are refused with MPE_ERR_UNSUPPORTED when their cursor is not NULL. */
+ * change from replay to replay in memory.  Buffers the one-launch kernel does not cover (records wider than 61 f32 / 30 f64
+ * columns, fewer than 256 transitions) are refused with MPE_ERR_UNSUPPORTED when their cursor is not NULL -- before
+ * anything is launched, like every error code < 0. */
 int mpe_replay_add_multi_cur_f32(int n_jobs, const mpe_replay_job *jobs, const int64_t *const *cursors, int64_t n,
                                  void *stream);
 int mpe_replay_add_multi_cur_f64(int n_jobs, const mpe_replay_job *jobs, const int64_t *const *cursors, int64_t n,
@@ -444,6 +476,8 @@ int mpe_stats_reduce(const double *stats, int64_t rows, int width, double *out, 
  * Limit: mpe_stats_rows(desc, B, dtype_bytes, buf->flags) * mpe_stats_width(desc) * 8 <= MPE_STATIC_SCRATCH_BYTES
  * (simple_tag f32: B <= 3 355 392), else MPE_ERR_SCRATCH and nothing is launched.  All calls on one GPU share that
  * GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not.
+ * Under HIP graph capture: make the FIRST call on a device outside the capture (it looks the array's address up with
+ * hipGetSymbolAddress, once per device; later calls only enqueue a memset and two kernels, all capturable).
  */
 #define MPE_STATIC_SCRATCH_BYTES (1 << 20)
 int mpe_env_step_stats_static(const mpe_scenario_desc *desc, int64_t B, int64_t ld, const mpe_buffers *buf,

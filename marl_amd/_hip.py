@@ -26,11 +26,12 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 9
+ABI_VERSION = 10
 FLAG_FORCE_TILE = 1
 FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
 FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
 FLAG_SILENT_COMM_ZERO = 8   # silent agents' comm rows already hold zeros: the step does not rewrite them
+FLAG_DEVICE_NOISE = 16      # u_noise / c_noise normals the caller does not supply are drawn inside the step kernels
 SPLIT_MAX_ENVS = 32768
 ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA = 0, 1, 2
 
@@ -66,7 +67,9 @@ class ScenarioDesc(C.Structure):
 class Buffers(C.Structure):
     """mpe_buffers (include/mpe_hip.h): device pointers of one batch."""
     _fields_ = [(n, C.c_void_p) for n in ('act', 'noise', 'pos', 'vel', 'comm', 'lforce', 'goal', 'obs', 'rew',
-                                          'info', 'stats', 'cnoise')] + [('flags', C.c_uint32)]
+                                          'info', 'stats', 'cnoise')] + [
+        ('flags', C.c_uint32), ('noise_step', C.c_uint32), ('noise_seed', C.c_uint64), ('env_id0', C.c_uint64),
+        ('noise_step_dev', C.c_void_p)]
 
     def __init__(self, flags=0, **tensors):
         super().__init__()
@@ -82,7 +85,7 @@ class Buffers(C.Structure):
         return self
 
 
-_BUFFER_NAMES = frozenset(n for n, _ in Buffers._fields_ if n != 'flags')
+_BUFFER_NAMES = frozenset(n for n, t in Buffers._fields_ if t is C.c_void_p)
 
 
 class ReplaySeg(C.Structure):
@@ -140,6 +143,8 @@ def _load():
         f.restype, f.argtypes = ci, [dp, i64, i64, ci, ci, ci, C.c_double, vp, vp, vp, vp]
         f = getattr(L, 'mpe_action_from_index_' + suf)  # desc, B, ld, ld_idx, idx, act, stream
         f.restype, f.argtypes = ci, [dp, i64, i64, i64, vp, vp, vp]
+        f = getattr(L, 'mpe_action_from_force_' + suf)  # desc, B, ld, ld_u, u, force_discrete, act, stream
+        f.restype, f.argtypes = ci, [dp, i64, i64, i64, vp, ci, vp, vp]
         f = getattr(L, 'mpe_action_force_discrete_' + suf)  # desc, B, ld, act, stream
         f.restype, f.argtypes = ci, [dp, i64, i64, vp, vp]
         f = getattr(L, 'mpe_replay_add_' + suf)       # capacity, next_idx, n, width, nseg, segs, ring, stream
@@ -169,11 +174,15 @@ def _load():
     L.mpe_env_step_stats_static.argtypes = [dp, i64, i64, bp, ci, vp, vp]
     L.mpe_desc_sizeof.restype = i64
     L.mpe_desc_sizeof.argtypes = []
+    L.mpe_buffers_sizeof.restype = i64
+    L.mpe_buffers_sizeof.argtypes = []
     if L.mpe_abi_version() != ABI_VERSION:
         raise ImportError('marl_amd: libmpe_hip.so ABI %d != expected %d' % (L.mpe_abi_version(), ABI_VERSION))
     if L.mpe_desc_sizeof() != C.sizeof(ScenarioDesc):
         raise ImportError('marl_amd: mpe_scenario_desc layout mismatch (%d vs %d bytes)'
                           % (L.mpe_desc_sizeof(), C.sizeof(ScenarioDesc)))
+    if L.mpe_buffers_sizeof() != C.sizeof(Buffers):
+        raise ImportError('marl_amd: mpe_buffers layout mismatch (%d vs %d bytes)' % (L.mpe_buffers_sizeof(), C.sizeof(Buffers)))
     return L
 
 

@@ -189,6 +189,12 @@ class World(object):
         self.dtype = None
         self.pos = self.vel = self.comm = self.act = self.noise = self.lforce = None
         self.cnoise = None         # optional caller-supplied normals for c_noise, [A, dim_c, B]
+        # u_noise / c_noise normals (core.py:147-148,229): `world.noise` / `world.cnoise` when the caller supplies them
+        # (recorded draws: parity mode); otherwise drawn INSIDE the step kernels, keyed by (seed, global env id,
+        # noise_step, agent, component) -- no extra launch, no noise rows in HBM, the same draws however the batch is
+        # sharded.  host_noise = True: torch's generator fills a buffer per step instead (the round-2 path).
+        self.host_noise = False
+        self.noise_step = 0        # steps taken so far (the Philox counter word of the in-kernel draws)
         self.act_rows = None       # [act_total, B]: the action buffer as the kernel indexes it
         self.act_row0 = self.act_dims = None
         self.goal = None           # int32 [B]: goal landmark index (agent.goal_a), goal scenarios only
@@ -285,6 +291,10 @@ class World(object):
         self.noise = None
         self._noise_buf = None
         self._cnoise_buf = None
+        # the part of the noise step counter that lives in device memory (a launch recorded in a HIP graph bakes its
+        # scalar arguments: graph.py moves this word between replays); _noise_dev_val is its host shadow
+        self._noise_step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self._noise_dev_val = 0
         self.obs = self.rew = self.info = self.obs_views = self.stats = None
         for i, e in enumerate(self.entities):
             e._world, e._index = self, i
@@ -302,7 +312,7 @@ class World(object):
     def set_flags(self, flags):
         """Per-call hints passed in ``mpe_buffers.flags`` (e.g. ``_hip.FLAG_FORCE_TILE``: run the generic LDS-tile
         kernel for a world that has a register-resident one).  The statistics rows depend on the kernel chosen."""
-        self._buf.flags = int(flags) | _hip.FLAG_SILENT_COMM_ZERO
+        self._buf.flags = (int(flags) & ~_hip.FLAG_DEVICE_NOISE) | _hip.FLAG_SILENT_COMM_ZERO
         if self.stats is not None:
             self.stats = None
             self.enable_stats()
@@ -438,12 +448,11 @@ class World(object):
         if self.obs is None:
             self._alloc_outputs()
         d = self.descriptor()
-        keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_env_step_' + _hip.suffix(self.dtype))
         self._run_scripted()
         b = self._buf
-        b.act, b.noise = self.act.data_ptr(), nptr
-        b.cnoise = self._cnoise_ptr()
+        b.act = self.act.data_ptr()
+        keep = self._bind_noise(b)
         b.info = self.info.data_ptr() if (want_info and self.info.numel()) else None
         b.stats = _hip.ptr(self.stats)
         self._clean_silent_comm()
@@ -502,10 +511,13 @@ class World(object):
         self._desc = None
         self._silent_comm_dirty = True      # an agent may have turned silent: its rows must read zeros again
 
+    def _has_c_noise(self):
+        return bool(self.dim_c) and any(a.c_noise and not a.silent for a in self.agents)
+
     def _cnoise_ptr(self):
         """Standard normals for c_noise (core.py:229), [A, dim_c, B]: ``world.cnoise`` if the caller set it
-        (recorded draws for parity), otherwise fresh torch.randn per step.  None when nobody has a c_noise."""
-        if not any(a.c_noise and not a.silent for a in self.agents) or not self.dim_c:
+        (recorded draws for parity); None otherwise: the kernels draw them (``host_noise``: torch.randn per step)."""
+        if not self._has_c_noise() or (self.cnoise is None and not self.host_noise):
             return None
         if self._cnoise_buf is None:
             self._cnoise_buf = self.rows(len(self.agents), self.dim_c)
@@ -516,9 +528,9 @@ class World(object):
         return self._cnoise_buf.data_ptr()
 
     def _noise_ptr(self):
-        """Standard normals for u_noise (core.py:147).  ``world.noise`` may be set by the caller
-        ([A,2,B], e.g. recorded draws for parity); otherwise fresh torch.randn per step."""
-        if not any(a.u_noise for a in self.agents):
+        """Standard normals for u_noise (core.py:147).  ``world.noise`` may be set by the caller ([A,2,B], e.g.
+        recorded draws for parity); None otherwise: the kernels draw them (``host_noise``: torch.randn per step)."""
+        if not any(a.u_noise for a in self.agents) or (self.noise is None and not self.host_noise):
             return None, None
         if self._noise_buf is None:
             self._noise_buf = self.rows(len(self.agents), 2)
@@ -528,16 +540,36 @@ class World(object):
             self._noise_buf.copy_(self.noise)
         return self._noise_buf, self._noise_buf.data_ptr()
 
+    def _bind_noise(self, b):
+        """The noise members of mpe_buffers for the step about to be launched; bumps the step counter."""
+        keep, b.noise = self._noise_ptr()
+        b.cnoise = self._cnoise_ptr()
+        if any(a.u_noise for a in self.agents) or self._has_c_noise():
+            b.flags |= _hip.FLAG_DEVICE_NOISE           # draws only what the caller did not supply
+            b.noise_seed, b.env_id0 = int(self.seed), int(self.env_id0)
+            b.noise_step = (self.noise_step - self._noise_dev_val) & 0xFFFFFFFF
+            b.noise_step_dev = self._noise_step_dev.data_ptr()
+        else:
+            b.flags &= ~_hip.FLAG_DEVICE_NOISE
+        self.noise_step = (self.noise_step + 1) & 0xFFFFFFFF
+        return keep
+
+    def _set_noise_dev(self, value):
+        """Moves the device part of the noise step counter (graph replays); eager steps subtract it again."""
+        value &= 0xFFFFFFFF
+        if value != self._noise_dev_val:
+            self._noise_step_dev.fill_(value - (1 << 32) if value >= (1 << 31) else value)
+            self._noise_dev_val = value
+
     # -- core.py:124-140 -----------------------------------------------------------------------------
     def step(self):
         """Advance every env by one tick using the actions in ``world.act``."""
         d = self.descriptor()
-        keep, nptr = self._noise_ptr()
         fn = getattr(_hip.lib, 'mpe_world_step_' + _hip.suffix(self.dtype))
         self._run_scripted()
         b = self._buf
-        b.act, b.noise = self.act.data_ptr(), nptr
-        b.cnoise = self._cnoise_ptr()
+        b.act = self.act.data_ptr()
+        keep = self._bind_noise(b)
         self._clean_silent_comm()
         with _hip.on_device(self.device):
             _hip.check(fn(d, self.num_envs, self.ld, b, _hip.stream_of(self.device)), 'mpe_world_step')

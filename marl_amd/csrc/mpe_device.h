@@ -62,7 +62,12 @@ struct KParams {
   T *pos, *vel, *comm, *lforce, *obs, *rew, *info;
   double *stats;
   int64_t B, ld;
-  uint32_t flags;  // mpe_buffers.flags (MPE_FLAG_*): the kernels read MPE_FLAG_SILENT_COMM_ZERO
+  uint32_t flags;  // mpe_buffers.flags (MPE_FLAG_*): the kernels read MPE_FLAG_SILENT_COMM_ZERO, MPE_FLAG_DEVICE_NOISE
+  // in-kernel u_noise / c_noise normals (MPE_FLAG_DEVICE_NOISE): Philox key, step counter (+ *nstep_dev when not
+  // NULL: the word a HIP-graph replay moves), global id of env 0 of this call
+  uint32_t nk0, nk1, nstep;
+  const uint32_t *nstep_dev;
+  uint64_t env_id0;
   DevDesc<T> d;
 };
 
@@ -454,14 +459,142 @@ __device__ __forceinline__ void leader_force(const KParams<T> &p, int a, int64_t
   }
 }
 
+// Philox4x32-10 (Salmon et al. 2011); restated in oracle/mpe_oracle.py:philox4x32_10.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 53-bit uniform in [0,1) from two words; p = -r + 2r*u (np.random.uniform's low + (high-low)*u).
+__device__ __forceinline__ double uniform_pm(uint32_t hi, uint32_t lo, double r) {
+  const double u = ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+  return -r + (2.0 * r) * u;
+}
+
+// ---- in-kernel standard normals for u_noise / c_noise (core.py:147-148,229: `np.random.randn(...) * noise`) -------------
+// The reference draws from numpy's global stream, which no device code can follow; with MPE_FLAG_DEVICE_NOISE and no
+// noise tensor from the caller the step kernels draw their own: Philox4x32-10 keyed like mpe_reset / the actor (counter =
+// (global env id lo, hi, step, stream word), key = seed), so a draw depends on WHICH env, step, agent and component it
+// is for and on nothing else -- not on the batch size, the sharding over GPUs or the kernel form -- then Box-Muller:
+//     u1 = (k53 + 1) 2^-53 in (0, 1], u2 = k53' 2^-53 in [0, 1)   (k53 from two words each, like uniform_pm)
+//     z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)
+// Stream words: 0x40000000 | agent -> (z0, z1) = the agent's (x, y) u_noise normals; 0x60000000 | agent << 8 | j -> the
+// c_noise normals of comm components 2j, 2j + 1.
+// f64: ln / sin / cos are written out in IEEE +, -, *, /, sqrt only, in a fixed order with contraction off, so that
+// oracle/mpe_oracle.py:device_normals restates them BIT FOR BIT in numpy (a libm call would not be the same function
+// on both sides).  ln u1 = e ln2 + 2 atanh((m - 1) / (m + 1)) with u1 = 2^e m, m in [sqrt(1/2), sqrt 2) (odd series to
+// s^21, |s| <= 0.172: truncation 1e-18); sin / cos of g pi/4, g in [0, 1], by Taylor polynomials (to a^17 / a^18:
+// truncation 1e-19) after an exact octant reduction of 8 u2.  Accuracy ~2e-16: far more than a noise term needs.
+// f32: the same Philox words, hardware v_log_f32 / v_sin_f32 / v_cos_f32 (the latter take revolutions: no 2 pi), u1 kept
+// to 24 significant bits whatever its magnitude; within ~1e-6 of the f64 normal.
+constexpr uint32_t kNoiseWordU = 0x40000000u, kNoiseWordC = 0x60000000u;
+
+__device__ __forceinline__ void normal_pair(const uint32_t w[4], double &z0, double &z1) {
+#pragma clang fp contract(off)
+  const double u1 = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6) + 1.0) * 0x1p-53;
+  const double u2 = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) * 0x1p-53;
+  int e;
+  double m = frexp(u1, &e);  // exact: m in [0.5, 1)
+  const bool low = m < 0.70710678118654757;
+  m = low ? m * 2.0 : m;
+  e = low ? e - 1 : e;
+  const double s = (m - 1.0) / (m + 1.0), z = s * s;
+  double P = 1.0 / 21.0;
+  P = P * z + 1.0 / 19.0;
+  P = P * z + 1.0 / 17.0;
+  P = P * z + 1.0 / 15.0;
+  P = P * z + 1.0 / 13.0;
+  P = P * z + 1.0 / 11.0;
+  P = P * z + 1.0 / 9.0;
+  P = P * z + 1.0 / 7.0;
+  P = P * z + 1.0 / 5.0;
+  P = P * z + 1.0 / 3.0;
+  P = P * z + 1.0;
+  const double lnu = (double)e * 0.69314718055994529 + 2.0 * (s * P);
+  const double r = sqrt(-2.0 * lnu);
+  const double t = u2 * 8.0;
+  const int k = (int)t;  // octant 0..7
+  const double f = t - (double)k;
+  const double g = (k & 1) ? 1.0 - f : f;
+  const double a = g * 0.78539816339744828, a2 = a * a;
+  double S = -1.0 / 355687428096000.0;  // -1/17!
+  S = S * a2 + 1.0 / 1307674368000.0;
+  S = S * a2 - 1.0 / 6227020800.0;
+  S = S * a2 + 1.0 / 39916800.0;
+  S = S * a2 - 1.0 / 362880.0;
+  S = S * a2 + 1.0 / 5040.0;
+  S = S * a2 - 1.0 / 120.0;
+  S = S * a2 + 1.0 / 6.0;   // sign folded below: S = 1/6 - a2/120 + ...
+  S = a - a * (a2 * S);     // sin a = a - a^3 (1/6 - a^2/120 + ...)
+  double Cc = -1.0 / 6402373705728000.0;  // -1/18!
+  Cc = Cc * a2 + 1.0 / 20922789888000.0;
+  Cc = Cc * a2 - 1.0 / 87178291200.0;
+  Cc = Cc * a2 + 1.0 / 479001600.0;
+  Cc = Cc * a2 - 1.0 / 3628800.0;
+  Cc = Cc * a2 + 1.0 / 40320.0;
+  Cc = Cc * a2 - 1.0 / 720.0;
+  Cc = Cc * a2 + 1.0 / 24.0;
+  Cc = Cc * a2 - 0.5;
+  Cc = Cc * a2 + 1.0;       // cos a
+  const bool swap = ((k + 1) >> 1) & 1;           // octants 1, 2, 5, 6: (cos, sin) = (+-sin a', +-cos a')
+  const double c0 = swap ? S : Cc, s0 = swap ? Cc : S;
+  z0 = r * ((((k + 2) >> 2) & 1) ? -c0 : c0);     // cos < 0 in octants 2..5
+  z1 = r * (k >= 4 ? -s0 : s0);                   // sin < 0 in octants 4..7
+}
+
+__device__ __forceinline__ void normal_pair(const uint32_t w[4], float &z0, float &z1) {
+  const float u1 = ((float)(w[0] >> 5) * 67108864.0f + (float)(w[1] >> 6) + 1.0f) * 0x1p-53f;
+  const float u2 = (float)w[2] * 0x1p-32f;
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989062f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+// Step counter of this launch (wave-uniform): the baked word plus the device word a graph replay moves.
+template <typename T>
+__device__ __forceinline__ uint32_t noise_step(const KParams<T> &p) {
+  return p.nstep + (p.nstep_dev != nullptr ? *p.nstep_dev : 0u);
+}
+template <typename T>
+__device__ __forceinline__ void device_normals(const KParams<T> &p, int64_t env, uint32_t step, uint32_t word, T &z0,
+                                               T &z1) {
+  const uint64_t gid = p.env_id0 + (uint64_t)env;
+  uint32_t w[4];
+  philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, word, p.nk0, p.nk1, w);
+  normal_pair(w, z0, z1);
+}
+template <typename T>
+__device__ __forceinline__ bool device_noise(const KParams<T> &p) { return (p.flags & MPE_FLAG_DEVICE_NOISE) != 0; }
+
 // agent.state.c of a speaking agent as this step leaves it (core.py:226-230): the comm entries of its action,
-// plus c_noise * standard normal when the agent has a c_noise; when only observing, the comm buffer.
+// plus c_noise * standard normal when the agent has a c_noise (the caller's tensor, else with MPE_FLAG_DEVICE_NOISE the
+// in-kernel draw: counter-based, so every reader of (agent, component, env) computes the same value); when only
+// observing, the comm buffer.
 template <typename T, bool DO_STEP>
 __device__ __forceinline__ T state_c(const KParams<T> &p, int a, int k, int64_t env) {
   if (!DO_STEP) return p.comm[(int64_t)(a * p.d.dim_c + k) * p.ld + env];
   T v = ld_stream(p.act + (int64_t)(p.d.cact_row0[a] + k) * p.ld + env);
-  if (p.cnoise != nullptr && p.d.c_noise[a] != T(0))
-    v = v + ld_stream(p.cnoise + (int64_t)(a * p.d.dim_c + k) * p.ld + env) * p.d.c_noise[a];
+  if (p.d.c_noise[a] != T(0)) {
+    if (p.cnoise != nullptr) {
+      v = v + ld_stream(p.cnoise + (int64_t)(a * p.d.dim_c + k) * p.ld + env) * p.d.c_noise[a];
+    } else if (device_noise(p)) {
+      T z0, z1;
+      device_normals<T>(p, env, noise_step(p), kNoiseWordC | ((uint32_t)a << 8) | (uint32_t)(k >> 1), z0, z1);
+      v = v + ((k & 1) ? z1 : z0) * p.d.c_noise[a];
+    }
+  }
   return v;
 }
 
@@ -550,30 +683,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
   return v;
-}
-
-// Philox4x32-10 (Salmon et al. 2011); restated in oracle/mpe_oracle.py:philox4x32_10.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// 53-bit uniform in [0,1) from two words; p = -r + 2r*u (np.random.uniform's low + (high-low)*u).
-__device__ __forceinline__ double uniform_pm(uint32_t hi, uint32_t lo, double r) {
-  const double u = ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
-  return -r + (2.0 * r) * u;
 }
 
 }  // namespace mpe

@@ -99,6 +99,7 @@ static int info_width_of(const mpe_scenario_desc *h) {
 
 extern "C" int mpe_abi_version(void) { return MPE_ABI_VERSION; }
 extern "C" int64_t mpe_desc_sizeof(void) { return (int64_t)sizeof(mpe_scenario_desc); }
+extern "C" int64_t mpe_buffers_sizeof(void) { return (int64_t)sizeof(mpe_buffers); }
 
 extern "C" const char *mpe_strerror(int code) {
   switch (code) {
@@ -440,9 +441,10 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, uint32_t flag
   const int threads = small_launch_threads(h, p.B, (int)sizeof(T), flags, &sv);
   if (threads != 0) {
     if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, p, s);
-    bool noise = false;
-    if (DO_STEP && p.noise != nullptr)
-      for (int a = 0; a < h->n_agents; ++a) noise = noise || h->u_noise[a] != 0.0;
+    int noise = 0;  // 1: the caller's normals, 2: drawn in the kernel (MPE_FLAG_DEVICE_NOISE)
+    if (DO_STEP && (p.noise != nullptr || (flags & MPE_FLAG_DEVICE_NOISE)))
+      for (int a = 0; a < h->n_agents; ++a)
+        if (h->u_noise[a] != 0.0) noise = p.noise != nullptr ? 1 : 2;
     return launch_stock_id<T, DO_STEP, DO_OBS>(sv, p, noise, small_id_splits(sv, p.B, flags), s);
   }
   return launch_tile_world<T, DO_STEP, DO_OBS>(h, p, s);
@@ -507,6 +509,14 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   p.B = B;
   p.ld = ld;
   p.flags = b->flags;
+  if (do_step && (b->flags & MPE_FLAG_DEVICE_NOISE)) {
+    if (misaligned<uint32_t>(b->noise_step_dev)) return MPE_ERR_ALIGN;
+    p.nk0 = (uint32_t)b->noise_seed;
+    p.nk1 = (uint32_t)(b->noise_seed >> 32);
+    p.nstep = b->noise_step;
+    p.nstep_dev = b->noise_step_dev;
+    p.env_id0 = b->env_id0;
+  }
   to_device_desc<T>(h, p.d);
   return MPE_OK;
 }
@@ -746,6 +756,33 @@ __global__ __launch_bounds__(256) void action_force_discrete_kernel(int64_t B, i
   for (int j = 0; j < 5; ++j) o[(int64_t)j * ld] = j == d ? T(1) : T(0);
 }
 
+// discrete_action_space == False (environment.py:191-192, "NEVER do here" in the fork's own comments, but a live switch):
+// the action of a movable agent IS the force command, `agent.action.u = action[0]` (2 entries), times the sensitivity.
+// Written as the 5-vector (0, u_x, 0, u_y, 0), whose default decode `a[1] - a[2]`, `a[3] - a[4]` returns u bit for bit
+// (x - 0 is exact; NaN and infinities pass through).  With force_discrete_action as well (:184-187 run first, on the
+// 2-vector): u = one_hot(argmax(u)), first maximum, a NaN wins.
+template <typename T>
+__global__ __launch_bounds__(256) void action_from_force_kernel(int64_t B, int64_t ld, int64_t ld_u, ActRows m,
+                                                                int force_discrete, const T *u, T *act) {
+  const int a = blockIdx.y;
+  if (!mpe::bit(m.movable, a)) return;
+  const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (env >= B) return;
+  T ux = __builtin_nontemporal_load(u + (int64_t)(2 * a) * ld_u + env);
+  T uy = __builtin_nontemporal_load(u + (int64_t)(2 * a + 1) * ld_u + env);
+  if (force_discrete) {
+    const bool second = uy > ux || (uy != uy && ux == ux);
+    ux = second ? T(0) : T(1);
+    uy = second ? T(1) : T(0);
+  }
+  T *o = act + (int64_t)m.row0[a] * ld + env;
+  o[0] = T(0);
+  o[ld] = ux;
+  o[2 * ld] = T(0);
+  o[3 * ld] = uy;
+  o[4 * ld] = T(0);
+}
+
 static void act_rows_of(const mpe_scenario_desc *h, ActRows &m) {
   memset(&m, 0, sizeof(m));
   for (int i = 0; i < h->n_agents; ++i) {
@@ -770,6 +807,27 @@ static int action_from_index_impl(const mpe_scenario_desc *h, int64_t B, int64_t
   act_rows_of(h, m);
   const dim3 grid((unsigned)((B + 255) / 256), (unsigned)h->n_agents), block(256);
   hipLaunchKernelGGL(action_from_index_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld, ld_idx, m, idx, (T *)act);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int action_from_force_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, int64_t ld_u, const void *u,
+                                  int force_discrete, void *act, void *stream) {
+  int rc = check_common<T>(h, B, ld);
+  if (rc) return rc;
+  if (!u || !act) return MPE_ERR_NULL;
+  if (ld_u < B) return MPE_ERR_BATCH;
+  if (misaligned<T>(u) || misaligned<T>(act)) return MPE_ERR_ALIGN;
+  // a movable agent that also speaks has a MultiDiscrete action: environment.py:161-168 hands the decode its first 5
+  // entries, `agent.action.u` becomes a 5-vector and World.integrate_state fails to add it to the 2-vector velocity
+  // (core.py:216, ValueError): nothing to reproduce
+  for (int i = 0; i < h->n_agents; ++i)
+    if (h->movable[i] && !h->silent[i]) return MPE_ERR_UNSUPPORTED;
+  ActRows m;
+  act_rows_of(h, m);
+  const dim3 grid((unsigned)((B + 255) / 256), (unsigned)h->n_agents), block(256);
+  hipLaunchKernelGGL(action_from_force_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld, ld_u, m,
+                     force_discrete ? 1 : 0, (const T *)u, (T *)act);
   return (int)hipGetLastError();
 }
 
@@ -1079,6 +1137,16 @@ static int replay_bind_segs(int nseg, const mpe_replay_seg *segs, ReplaySegs &sg
   return rows;
 }
 
+// Does the one-launch append kernel cover this job?  Records of <= kReplayFlatCols columns whose 256-transition tile
+// (dynamic LDS) fits 64 KiB TOGETHER WITH the kernel's static column tables (s_src / s_es), and a full tile to store.
+constexpr size_t kReplayStaticLds = (size_t)kReplayFlatCols * (sizeof(void *) + sizeof(int64_t));
+template <typename T>
+static bool replay_one_launch(const mpe_replay_job &j, int64_t n) {
+  const int64_t skip = n > j.capacity ? n - j.capacity : 0;
+  return j.width <= kReplayFlatCols && (size_t)j.width * 257 * sizeof(T) + kReplayStaticLds <= 64 * 1024 &&
+         n - skip >= 256;
+}
+
 template <typename T>
 static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, const int64_t *const *cursors, int64_t n,
                                  void *stream) {
@@ -1092,6 +1160,8 @@ static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, const i
     if (!j.ring) return MPE_ERR_NULL;
     if (j.capacity < 1 || j.next_idx < 0 || j.next_idx >= j.capacity || rows != j.width) return MPE_ERR_ARG;
     if (misaligned<T>(j.ring)) return MPE_ERR_ALIGN;
+    // the single-buffer kernels take no device cursor: refused here, before anything is launched
+    if (n > 0 && cursors && cursors[i] && !replay_one_launch<T>(j, n)) return MPE_ERR_UNSUPPORTED;
   }
   if (n == 0) return MPE_OK;
   int i0 = 0;
@@ -1104,7 +1174,7 @@ static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, const i
     while (i0 + nj < n_jobs && nj < kReplayMaxJobs) {
       const mpe_replay_job &j = jobs[i0 + nj];
       const int64_t skip = n > j.capacity ? n - j.capacity : 0;
-      if (j.width > kReplayFlatCols || (size_t)j.width * 257 * sizeof(T) > 64 * 1024 || n - skip < 256) break;
+      if (!replay_one_launch<T>(j, n)) break;
       replay_bind_segs<T>(j.nseg, j.segs, tab.sg[nj]);
       tab.capacity[nj] = j.capacity;
       tab.next_idx[nj] = j.next_idx;
@@ -1118,7 +1188,6 @@ static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, const i
     }
     if (nj == 0) {
       const mpe_replay_job &j = jobs[i0];
-      if (cursors && cursors[i0]) return MPE_ERR_UNSUPPORTED;  // the single-buffer kernels take no device cursor
       const int rc = replay_add_impl<T>(j.capacity, j.next_idx, n, j.width, j.nseg, j.segs, j.ring, stream);
       if (rc) return rc;
       ++i0;
@@ -1274,6 +1343,10 @@ static int scratch_of_current_device(double **out) {
 template <typename T>
 static int env_step_stats_static_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, const mpe_buffers *b,
                                       double *stats_out, hipStream_t stream) {
+  if (!b) return MPE_ERR_NULL;
+  mpe_buffers local = *b;  // buf->stats is documented as ignored: whatever it holds must not reach the pointer checks
+  local.stats = nullptr;
+  b = &local;
   KParams<T> p{};
   int rc = bind_buffers<T>(h, B, ld, b, true, true, p);
   if (rc) return rc;
@@ -1332,6 +1405,10 @@ extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, 
   extern "C" int mpe_action_from_index_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, int64_t ld_idx, \
                                              const int32_t *idx, void *act, void *stream) {                    \
     return action_from_index_impl<T>(d, B, ld, ld_idx, idx, act, stream);                                      \
+  }                                                                                                            \
+  extern "C" int mpe_action_from_force_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, int64_t ld_u,    \
+                                             const void *u, int force_discrete, void *act, void *stream) {     \
+    return action_from_force_impl<T>(d, B, ld, ld_u, u, force_discrete, act, stream);                          \
   }                                                                                                            \
   extern "C" int mpe_action_force_discrete_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, void *act,  \
                                                  void *stream) {                                               \

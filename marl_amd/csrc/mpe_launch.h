@@ -62,7 +62,7 @@ int launch_tile_world(const mpe_scenario_desc *h, const KParams<T> &p, hipStream
 // Run the register kernel `sv` (one env per lane, stock shapes): the stock scenarios' kernels are defined in
 // mpe_small_f32.hip / mpe_small_f64.hip, the command-hierarchy ones in mpe_hier_f32.hip / mpe_hier_f64.hip.
 template <typename T, bool DO_STEP, bool DO_OBS>
-int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, bool split, hipStream_t s);
+int launch_stock_id(SmallId sv, const KParams<T> &p, int noise, bool split, hipStream_t s);
 template <typename T, bool DO_STEP, bool DO_OBS>
 int launch_hier_id(SmallId sv, const KParams<T> &p, hipStream_t s);
 inline bool small_id_is_hier(SmallId sv) { return (sv >= HIER_FIRST && sv <= HIER_LAST) || sv == MOVING_6_4_3 || sv == MOVING_8_4_7; }

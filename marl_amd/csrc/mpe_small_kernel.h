@@ -47,7 +47,8 @@ constexpr int small_wave_cap(int kind, int elem_bytes) {
 #define MPE_SMALL_ATTR __attribute__((amdgpu_waves_per_eu(1, small_wave_cap(KIND, (int)sizeof(T)))))
 #endif
 
-template <typename T, int KIND, int A, int L, int NADV, int THREADS, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
+// NOISE: 0 = no u_noise, 1 = the caller's normals (p.noise), 2 = drawn in the kernel (MPE_FLAG_DEVICE_NOISE, mpe_device.h)
+template <typename T, int KIND, int A, int L, int NADV, int THREADS, int NOISE, bool DO_STEP, bool DO_OBS>
 __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr bool TAG = KIND == MPE_SIMPLE_TAG;
@@ -91,9 +92,18 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
       a2[a] = wact.ld_stream(5 * a + 2, lo);
       a3[a] = wact.ld_stream(5 * a + 3, lo);
       a4[a] = wact.ld_stream(5 * a + 4, lo);
-      if (HAS_NOISE) {
+      if (NOISE == 1) {
         nx[a] = wnoise.ld_stream(2 * a, lo);
         ny[a] = wnoise.ld_stream(2 * a + 1, lo);
+      }
+    }
+    if (NOISE == 2) {  // tail lanes draw env B - 1's normals and store nothing
+      const int64_t env = active ? blk0 + threadIdx.x : p.B - 1;
+      const uint32_t step = noise_step(p);
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        nx[a] = ny[a] = T(0);
+        if (d.u_noise[a] != T(0)) device_normals<T>(p, env, step, kNoiseWordU | (uint32_t)a, nx[a], ny[a]);
       }
     }
     T Fx[A], Fy[A];
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
     for (int a = 0; a < A; ++a) {  // environment.py:188-196, core.py:147-148
       Fx[a] = (a1[a] - a2[a]) * d.accel[a];
       Fy[a] = (a3[a] - a4[a]) * d.accel[a];
-      if (HAS_NOISE) {  // u_noise[a] == 0 encodes None: u + 0.0*n would differ only for n = inf/nan
+      if (NOISE != 0) {  // u_noise[a] == 0 encodes None: u + 0.0*n would differ only for n = inf/nan
         Fx[a] = d.u_noise[a] != T(0) ? Fx[a] + nx[a] * d.u_noise[a] : Fx[a];
         Fy[a] = d.u_noise[a] != T(0) ? Fy[a] + ny[a] * d.u_noise[a] : Fy[a];
       }

@@ -12,24 +12,38 @@
 namespace mpe {
 
 template <typename T, int KIND, int A, int L, int NADV, bool DO_STEP, bool DO_OBS>
-static int launch_small(const KParams<T> &p, bool noise, hipStream_t s) {
+static int launch_small(const KParams<T> &p, int noise, hipStream_t s) {
   constexpr int THREADS = kSmallThreads;
   const dim3 grid((unsigned)((p.B + THREADS - 1) / THREADS)), block(THREADS);
-  if (noise)
-    hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  if constexpr (DO_STEP) {  // noise: 0 none, 1 the caller's normals, 2 drawn in the kernel
+    if (noise == 1) {
+      hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, 1, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
+    if (noise == 2) {
+      hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, 2, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, 0, DO_STEP, DO_OBS>), grid, block, 0, s, p);
   return (int)hipGetLastError();
 }
 
 // small batches: one agent per wavefront, 64 envs per workgroup (mpe_split_kernel.h)
 template <typename T, int KIND, int A, int L, int NADV, bool DO_STEP, bool DO_OBS>
-static int launch_split(const KParams<T> &p, bool noise, hipStream_t s) {
+static int launch_split(const KParams<T> &p, int noise, hipStream_t s) {
   const dim3 grid((unsigned)((p.B + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitEnvs * A);
-  if (noise)
-    hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, true, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, false, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  if constexpr (DO_STEP) {
+    if (noise == 1) {
+      hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, 1, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
+    if (noise == 2) {
+      hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, 2, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((split_kernel<T, KIND, A, L, NADV, 0, DO_STEP, DO_OBS>), grid, block, 0, s, p);
   return (int)hipGetLastError();
 }
 
@@ -41,7 +55,7 @@ static int launch_comm(const KParams<T> &p, hipStream_t s) {
 }
 
 template <typename T, bool DO_STEP, bool DO_OBS>
-int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, bool split, hipStream_t s) {
+int launch_stock_id(SmallId sv, const KParams<T> &p, int noise, bool split, hipStream_t s) {
   const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
   switch (sv) {
     case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
@@ -67,8 +81,8 @@ int launch_stock_id(SmallId sv, const KParams<T> &p, bool noise, bool split, hip
   }
 }
 
-template int launch_stock_id<MPE_TU_T, true, false>(SmallId, const KParams<MPE_TU_T> &, bool, bool, hipStream_t);
-template int launch_stock_id<MPE_TU_T, false, true>(SmallId, const KParams<MPE_TU_T> &, bool, bool, hipStream_t);
-template int launch_stock_id<MPE_TU_T, true, true>(SmallId, const KParams<MPE_TU_T> &, bool, bool, hipStream_t);
+template int launch_stock_id<MPE_TU_T, true, false>(SmallId, const KParams<MPE_TU_T> &, int, bool, hipStream_t);
+template int launch_stock_id<MPE_TU_T, false, true>(SmallId, const KParams<MPE_TU_T> &, int, bool, hipStream_t);
+template int launch_stock_id<MPE_TU_T, true, true>(SmallId, const KParams<MPE_TU_T> &, int, bool, hipStream_t);
 
 }  // namespace mpe

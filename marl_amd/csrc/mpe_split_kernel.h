@@ -24,7 +24,7 @@
 
 namespace mpe {
 
-template <typename T, int KIND, int A, int L, int NADV, bool HAS_NOISE, bool DO_STEP, bool DO_OBS>
+template <typename T, int KIND, int A, int L, int NADV, int NOISE, bool DO_STEP, bool DO_OBS>
 __global__ __launch_bounds__(64 * A) void split_kernel(const KParams<T> p) {
   static_assert(KIND == MPE_SIMPLE_TAG || KIND == MPE_SIMPLE_SPREAD, "north-star worlds only");
   constexpr int E = A + L;
@@ -64,8 +64,14 @@ __global__ __launch_bounds__(64 * A) void split_kernel(const KParams<T> p) {
     const T a1 = wact.ld_stream(5 * me + 1, lo), a2 = wact.ld_stream(5 * me + 2, lo);  // environment.py:188-196
     const T a3 = wact.ld_stream(5 * me + 3, lo), a4 = wact.ld_stream(5 * me + 4, lo);
     T Fx = (a1 - a2) * d.accel[me], Fy = (a3 - a4) * d.accel[me];
-    if (HAS_NOISE) {  // core.py:147-148; u_noise == 0 encodes None
-      const T nx = wnoise.ld_stream(2 * me, lo), ny = wnoise.ld_stream(2 * me + 1, lo);
+    if (NOISE != 0) {  // core.py:147-148; u_noise == 0 encodes None.  1: the caller's normals, 2: drawn here
+      T nx = T(0), ny = T(0);
+      if (NOISE == 1) {
+        nx = wnoise.ld_stream(2 * me, lo);
+        ny = wnoise.ld_stream(2 * me + 1, lo);
+      } else if (d.u_noise[me] != T(0)) {
+        device_normals<T>(p, active ? blk0 + lane : p.B - 1, noise_step(p), kNoiseWordU | (uint32_t)me, nx, ny);
+      }
       Fx = d.u_noise[me] != T(0) ? Fx + nx * d.u_noise[me] : Fx;
       Fy = d.u_noise[me] != T(0) ? Fy + ny * d.u_noise[me] : Fy;
     }

@@ -214,6 +214,9 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         }
       }
     };
+    // u_noise normals drawn in the kernel (MPE_FLAG_DEVICE_NOISE, no tensor from the caller): at the point of use
+    const bool draw_u = DO_STEP && p.noise == nullptr && device_noise(p);
+    const uint32_t nstep = draw_u ? noise_step(p) : 0u;
     AgentIn nxt;
     if (DO_STEP && chunk < A) fetch(chunk, nxt);
     if (!DO_STEP) {
@@ -237,6 +240,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           if (p.noise != nullptr && d.u_noise[a] != T(0)) {
             Fx = Fx + cur.nx * d.u_noise[a];
             Fy = Fy + cur.ny * d.u_noise[a];
+          } else if (draw_u && d.u_noise[a] != T(0)) {
+            T nx, ny;
+            device_normals<T>(p, ge, nstep, kNoiseWordU | (uint32_t)a, nx, ny);
+            Fx = Fx + nx * d.u_noise[a];
+            Fy = Fy + ny * d.u_noise[a];
           }
           // core.py:153-194
           if (has_lf) {
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             if (active) st_state(p.pos + (int64_t)r * ld + env, np_);
           }
         }
-        if (p.comm != nullptr && active) {  // core.py:226-230 (c_noise is rejected on the host)
+        if (p.comm != nullptr && active) {  // core.py:226-230
           const bool mute = !HIER || bit(d.silent, a);
           if (mute && !rewrite_silent_comm(p)) continue;
           for (int c = 0; c < d.dim_c; ++c)

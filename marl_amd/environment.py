@@ -52,6 +52,7 @@ class MultiAgentEnv(object):
         self.time = 0
         self.obs_r = observation_radius
         self._idx = None          # int32 [n, ld]: the integer actions of discrete_action_input
+        self._u = None            # [A, 2, ld]: the force commands of discrete_action_space = False
 
         # fused path: every callback is a built-in scenario's own method
         owners = {getattr(cb, '__self__', None) for cb in (reset_callback, reward_callback, observation_callback)}
@@ -93,6 +94,8 @@ class MultiAgentEnv(object):
     def _set_actions(self, action_n):
         if self.discrete_action_input:               # environment.py:176-182: one integer per agent
             return self._set_index_actions(action_n)
+        if not self.discrete_action_space:           # environment.py:191-192: the action is the force command itself
+            return self._set_force_actions(action_n)
         self._copy_actions(action_n)
         if self.force_discrete_action:               # environment.py:184-187: argmax -> one-hot, in place like the reference
             w = self.world
@@ -132,6 +135,45 @@ class MultiAgentEnv(object):
         with _hip.on_device(w.device):
             _hip.check(fn(w.descriptor(), w.num_envs, w.ld, w.ld, self._idx.data_ptr(), w.act.data_ptr(),
                           _hip.stream_of(w.device)), 'mpe_action_from_index')
+
+    def _set_force_actions(self, action_n):
+        """``env.discrete_action_space = False`` (environment.py:29,191-192; the spaces were built Discrete at
+        construction, as in the reference, where the switch can only be flipped afterwards): the action of agent i is
+        its force command ``u`` -- ``[B, 2]`` per agent (a list), or one ``[B, n, 2]`` / ``[n, 2, B]`` tensor --,
+        multiplied by the sensitivity like any other; ``force_discrete_action`` first turns it into
+        one_hot(argmax(u)) (:184-187).  The reference scales the CALLER's array in place (``agent.action.u = action[0]``,
+        ``u *= sensitivity``); here the caller's tensors are only read."""
+        w = self.world
+        if any(a.movable and not a.silent for a in w.agents):
+            # environment.py:161-168: the first 5 entries of the MultiDiscrete action become u; core.py:216 then adds a
+            # 5-vector to the 2-vector velocity
+            raise ValueError('discrete_action_space = False with a movable speaking agent: the reference fails in '
+                             'integrate_state (core.py:216: operands could not be broadcast together)')
+        if self._u is None:
+            self._u = torch.zeros(len(w.agents), 2, w.ld, dtype=w.dtype, device=w.device)
+        u = self._u[:, :, :self.num_envs]
+        if torch.is_tensor(action_n) and action_n.dim() == 3:
+            if not self._all_policy:
+                raise ValueError('with scripted agents pass one action per POLICY agent (a list, environment.py:96-98)')
+            if tuple(action_n.shape) == (self.num_envs, self.n, 2) and action_n.stride() != u.stride():
+                action_n = action_n.permute(1, 2, 0)
+            if tuple(action_n.shape) != (self.n, 2, self.num_envs):
+                raise ValueError('force commands must be [num_envs, n, 2] or [n, 2, num_envs]')
+            u.copy_(action_n)
+        else:
+            if len(action_n) != self.n:
+                raise ValueError('need one action per agent')
+            for i, a in zip(self._pidx, action_n):
+                a = torch.as_tensor(a, dtype=w.dtype, device=w.device)
+                if a.shape[-1] != 2:
+                    raise ValueError('a force command has dim_p = 2 components, got %s' % (tuple(a.shape),))
+                u[i].copy_(a.expand(self.num_envs, 2).t())
+        if w.act.data_ptr() != self._own_act.data_ptr():
+            w.act = self._own_act
+        fn = getattr(_hip.lib, 'mpe_action_from_force_' + _hip.suffix(w.dtype))
+        with _hip.on_device(w.device):
+            _hip.check(fn(w.descriptor(), w.num_envs, w.ld, w.ld, self._u.data_ptr(), int(bool(self.force_discrete_action)),
+                          w.act.data_ptr(), _hip.stream_of(w.device)), 'mpe_action_from_force')
 
     def _copy_actions(self, action_n):
         act = self.world.act

@@ -28,39 +28,46 @@ class CapturedSteps(object):
         self.env, self.actions, self.K = env, list(action_seq), len(action_seq)
         if w.obs is None:
             w._alloc_outputs()
-        state = [t.clone() for t in (w.pos, w.vel)] + [None if t is None else t.clone() for t in (w.lforce, w.stats)]
-        env.step(self.actions[0])                  # every lazy one-time cost (module load, LDS limit) before the capture
-        self._restore(state)
-        self._slot0 = w._obs_slot
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: another thread's HIP calls (the RCCL watchdog of torch.distributed polls events) must not
-        # invalidate the capture; everything enqueued so far is drained first
-        torch.cuda.synchronize(w.device)
-        with _hip.on_device(w.device):
-            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-                for a in self.actions:
-                    self.last = env.step(a)
-        self._slot_after = w._obs_slot
-        self._restore(state)                       # a capture executes nothing, but the bookkeeping moved: put it back
-        w._obs_slot = self._slot0
+        # everything a step moves: the warm-up step and the capture itself (which executes nothing, but runs the host
+        # side of K steps) must leave the world exactly as it was, also when the capture fails
+        state = [None if t is None else t.clone()
+                 for t in (w.pos, w.vel, w.lforce, w.stats, w.comm if w._comm_arg is not None else None)]
+        host = (w._obs_slot, w.act, w.noise_step, w._gather_tick)
+        try:
+            env.step(self.actions[0])              # every lazy one-time cost (module load, LDS limit) before the capture
+            self._restore(state, host)
+            # a recorded launch bakes noise_step: what moves from replay to replay is the device word (core.py)
+            self._noise_base = (w.noise_step - w._noise_dev_val) & 0xFFFFFFFF
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: another thread's HIP calls (the RCCL watchdog of torch.distributed polls events) must not
+            # invalidate the capture; everything enqueued so far is drained first
+            torch.cuda.synchronize(w.device)
+            with _hip.on_device(w.device):
+                with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                    for a in self.actions:
+                        self.last = env.step(a)
+            self._slot_after = w._obs_slot
+        finally:
+            self._restore(state, host)
+
+    def _restore(self, state, host):
+        w = self.env.world
+        for t, saved in zip((w.pos, w.vel, w.lforce, w.stats, w.comm), state):
+            if saved is not None and t is not None:
+                t.copy_(saved)
+        w._obs_slot, w.act, w.noise_step, gather_tick = host
         w.obs, w.obs_views = w._obs_pair[w._obs_slot], w._views_pair[w._obs_slot]
         w._buf.set(obs=w.obs)
-
-    def _restore(self, state):
-        w = self.env.world
-        w.pos.copy_(state[0])
-        w.vel.copy_(state[1])
-        if state[2] is not None:
-            w.lforce.copy_(state[2])
-        if state[3] is not None and w.stats is not None:
-            w.stats.copy_(state[3])
-        w.mark_dirty()
+        w.mark_dirty()                             # the output buffers hold the warm-up step's results: not current
 
     def replay(self):
         """Runs the K steps; the world's Python-side bookkeeping ends up as after K ``env.step`` calls."""
         w = self.env.world
         w._clean_silent_comm()
+        if w._buf.flags & _hip.FLAG_DEVICE_NOISE:
+            w._set_noise_dev(w.noise_step - self._noise_base)
         self.graph.replay()
+        w.noise_step = (w.noise_step + self.K) & 0xFFFFFFFF
         w._obs_slot = self._slot_after
         w.obs, w.obs_views = w._obs_pair[w._obs_slot], w._views_pair[w._obs_slot]
         w._buf.set(obs=w.obs)
@@ -97,41 +104,51 @@ class CapturedTrainSteps(object):
         if not env._fused:
             raise RuntimeError('CapturedTrainSteps needs the fused step (built-in scenario callbacks)')
         w = env.world
+        if w.scripted_agents:
+            raise RuntimeError('CapturedTrainSteps cannot record scripted agents (their action_callback is host code)')
         self.env, self.trainers, self.K = env, list(trainers), int(K)
         self.buffers = [tr.replay_buffer for tr in self.trainers]
         if any(tr._packed is None for tr in self.trainers) or any(b._ring is None for b in self.buffers):
             raise RuntimeError('run one eager act_all / env.step / add_all iteration before capturing')
         if w.obs is None or w._obs_tick != w._tick:
             raise RuntimeError('capture right after env.reset() or env.step(): the observations must be current')
+        for b in self.buffers:      # what add_all(cursors=True) would refuse in the middle of the capture, refused up front
+            if not b.one_launch_capable(w.num_envs):
+                raise RuntimeError('CapturedTrainSteps: a replay record of %d columns / a batch of %d envs is outside the '
+                                   'one-launch append (mpe_replay_add_multi_cur_*: <= 61 f32 / 30 f64 columns, >= 256 '
+                                   'transitions)' % (b._ring.shape[1], w.num_envs))
         self.ctr = torch.zeros(1, dtype=torch.int32, device=w.device)
         for b in self.buffers:
             b.device_cursor().zero_()
         self._base_calls = self.trainers[0]._act_calls
         self._base_idx = [b._next_idx for b in self.buffers]
         self._slot0 = w._obs_slot
+        self._noise_base = (w.noise_step - w._noise_dev_val) & 0xFFFFFFFF
         host = ([tr._act_calls for tr in self.trainers], [(b._next_idx, b._len, getattr(b, '_keep', None)) for b in self.buffers],
-                (w._tick, w._obs_tick, w._gather_tick, w.act))
+                (w._tick, w._obs_tick, w._gather_tick, w.act, w.noise_step))
         self.graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(w.device)
-        with _hip.on_device(w.device):
-            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-                obs_n = list(w.obs_views)
-                for _ in range(self.K):
-                    action_n = act_all(self.trainers, obs_n, out=env.action_views, kernel=kernel, counter_dev=self.ctr)
-                    new_obs_n, rew_n, done_n, info_n = env.step(action_n)
-                    add_all(self.buffers, obs_n, action_n, rew_n, new_obs_n, done_n, cursors=True)
-                    obs_n = new_obs_n
-                self.last = (new_obs_n, rew_n, done_n, info_n)
-        self._slot_after = w._obs_slot
-        self._act_after = w.act
-        self._n = w.num_envs
-        # a capture executes nothing, but the host-side bookkeeping moved: put it back
-        for tr, c in zip(self.trainers, host[0]):
-            tr._act_calls = c
-        for b, (i, l, k) in zip(self.buffers, host[1]):
-            b._next_idx, b._len, b._keep = i, l, k
-        w._tick, w._obs_tick, w._gather_tick, w.act = host[2]
-        self._set_slot(self._slot0)
+        try:
+            with _hip.on_device(w.device):
+                with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                    obs_n = [w.obs_views[i] for i in env._pidx]
+                    for _ in range(self.K):
+                        action_n = act_all(self.trainers, obs_n, out=env.action_views, kernel=kernel, counter_dev=self.ctr)
+                        new_obs_n, rew_n, done_n, info_n = env.step(action_n)
+                        add_all(self.buffers, obs_n, action_n, rew_n, new_obs_n, done_n, cursors=True)
+                        obs_n = new_obs_n
+                    self.last = (new_obs_n, rew_n, done_n, info_n)
+            self._slot_after = w._obs_slot
+            self._act_after = w.act
+            self._n = w.num_envs
+        finally:
+            # a capture executes nothing, but the host-side bookkeeping moved: put it back (also after a failed capture)
+            for tr, c in zip(self.trainers, host[0]):
+                tr._act_calls = c
+            for b, (i, l, k) in zip(self.buffers, host[1]):
+                b._next_idx, b._len, b._keep = i, l, k
+            w._tick, w._obs_tick, w._gather_tick, w.act, w.noise_step = host[2]
+            self._set_slot(self._slot0)
 
     def _set_slot(self, slot):
         w = self.env.world
@@ -152,7 +169,10 @@ class CapturedTrainSteps(object):
         for b, base in zip(self.buffers, self._base_idx):
             b.device_cursor().fill_((b._next_idx - base) % b._maxsize)
         w._clean_silent_comm()
+        if w._buf.flags & _hip.FLAG_DEVICE_NOISE:
+            w._set_noise_dev(w.noise_step - self._noise_base)
         self.graph.replay()
+        w.noise_step = (w.noise_step + self.K) & 0xFFFFFFFF
         for b in self.buffers:
             b.device_cursor().zero_()                  # eager add_all(cursors=True) calls see no offset
         for tr in self.trainers:

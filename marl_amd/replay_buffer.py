@@ -42,6 +42,14 @@ class ReplayBuffer(object):
             self._cursor_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         return self._cursor_dev
 
+    def one_launch_capable(self, n):
+        """Whether ``add_all(..., cursors=True)`` of n transitions can append to this (already allocated) buffer: the
+        one-launch kernel of mpe_replay_add_multi_cur_* holds a 256-transition tile of the record plus its column tables
+        in 64 KiB of LDS (records of <= 61 f32 / 30 f64 columns) and needs a full tile."""
+        width = self._ring.shape[1]
+        esize = self._ring.element_size()
+        return width * 257 * esize + 160 * 16 <= 64 * 1024 and min(n, self._maxsize) >= 256
+
     def _seg(self, t, n):
         """mpe_replay_seg of a [n, d] / [n] tensor with arbitrary strides."""
         if not torch.is_tensor(t):             # e.g. the scalar False of done_n (environment.py:108)

@@ -370,6 +370,7 @@ class SerialEnv:
         self.scripted = {}
         self.discrete_action_input = False   # environment.py:31: the action is an integer
         self.force_discrete_action = False   # environment.py:33: argmax -> one-hot before the decode
+        self.discrete_action_space = True    # environment.py:29; False: the action IS the force command (:191-192)
 
     # -- state helpers ----------------------------------------------------------------
     def set_state(self, pos, vel):
@@ -417,6 +418,18 @@ class SerialEnv:
                 if action == 4: u[1] = +1.0
                 u *= 5.0 if agent.accel is None else agent.accel
             agent.u = u
+            agent.c_act = np.zeros(self.spec.dim_c)
+            return
+        if agent.movable and not self.discrete_action_space:
+            # environment.py:184-187,191-196 with the Discrete space built at construction: `action = [action]`, the
+            # argmax (if forced) runs on that vector, `agent.action.u = action[0]` (the caller's array), `u *= sensitivity`
+            assert agent.silent, 'a MultiDiscrete action would make u its first 5 entries (core.py:216 then fails)'
+            action = np.asarray(action, dtype=np.float64)
+            if self.force_discrete_action:
+                d = np.argmax(action)
+                action[:] = 0.0
+                action[d] = 1.0
+            agent.u = action * (5.0 if agent.accel is None else agent.accel)
             agent.c_act = np.zeros(self.spec.dim_c)
             return
         if agent.movable:                 # environment.py:174-197: only a movable agent has the physical part
@@ -929,9 +942,15 @@ def _norm2_blas(d0, d1):
 class BatchedOracle:
     """pos[E,2,B], vel[A,2,B]; act[A,5,B]; noise[A,2,B] standard normals (or None)."""
 
-    def __init__(self, spec: ScenarioSpec, dtype=np.float64, discrete_action_input=False, force_discrete_action=False):
+    def __init__(self, spec: ScenarioSpec, dtype=np.float64, discrete_action_input=False, force_discrete_action=False,
+                 discrete_action_space=True):
         self.spec = spec
         self.dt = np.dtype(dtype).type
+        # environment.py:29,191-192.  False: rows 0, 1 of an agent's 5 physical rows hold its force command u
+        self.discrete_action_space = discrete_action_space
+        if not discrete_action_space:
+            assert all(sl or not mv for sl, mv in zip(spec.silent, spec.movable)), 'core.py:216 fails for a 5-vector u'
+            assert not discrete_action_input
         # environment.py:31,33.  With discrete_action_input the physical rows of an agent hold its integer action
         # (row 0 is read); with force_discrete_action they are replaced by one_hot(argmax) before the decode.
         self.discrete_action_input = discrete_action_input
@@ -943,6 +962,14 @@ class BatchedOracle:
         """The 5 physical rows a[5,B] of one movable agent -> the 5 rows the default decode (environment.py:188-190)
         reads: unchanged, or environment.py:176-182 / :184-187 first."""
         T = self.dt
+        if not self.discrete_action_space:          # u = action[0] (after the forced argmax, :184-187): (0, ux, 0, uy, 0)
+            ux, uy = a[0], a[1]
+            if self.force_discrete_action:
+                second = np.argmax(np.stack([ux, uy]), axis=0) == 1
+                ux, uy = np.where(second, T(0), T(1)), np.where(second, T(1), T(0))
+            z = np.zeros_like(a)
+            z[1], z[3] = ux, uy
+            return z
         if self.discrete_action_input:
             k = a[0]
             z = np.zeros_like(a)
@@ -1670,3 +1697,89 @@ def reset_positions(spec: ScenarioSpec, seed: int, episode, env_ids, dtype=np.fl
         pos[e, 0] = (-r + (2.0 * r) * _u01(w[0], w[1])).astype(dtype)
         pos[e, 1] = (-r + (2.0 * r) * _u01(w[2], w[3])).astype(dtype)
     return pos
+
+
+# --------------------------------------------------------------------------------------
+# In-kernel u_noise / c_noise normals (MPE_FLAG_DEVICE_NOISE; this build's own spec, no reference counterpart: the
+# reference draws np.random.randn from the global stream, core.py:147-148,229).  Restated operation by operation from
+# marl_amd/csrc/mpe_device.h:normal_pair -- only IEEE +, -, *, /, sqrt on float64, no fused operations -- so the f64
+# kernels' normals are reproduced BIT FOR BIT.
+# --------------------------------------------------------------------------------------
+NOISE_WORD_U, NOISE_WORD_C = 0x40000000, 0x60000000
+
+
+def normal_pair(w):
+    """Box-Muller on four Philox words (uint32 arrays) -> (z0, z1) float64."""
+    f8 = np.float64
+    u1 = ((w[0] >> np.uint32(5)).astype(f8) * 67108864.0 + (w[1] >> np.uint32(6)).astype(f8) + 1.0) * 2.0 ** -53
+    u2 = ((w[2] >> np.uint32(5)).astype(f8) * 67108864.0 + (w[3] >> np.uint32(6)).astype(f8)) * 2.0 ** -53
+    m, e = np.frexp(u1)                                   # exact: m in [0.5, 1)
+    low = m < 0.70710678118654757
+    m = np.where(low, m * 2.0, m)
+    e = np.where(low, e - 1, e)
+    s = (m - 1.0) / (m + 1.0)
+    z = s * s
+    P = np.full_like(z, 1.0 / 21.0)
+    for c in (19.0, 17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0):
+        P = P * z + 1.0 / c
+    P = P * z + 1.0
+    lnu = e.astype(f8) * 0.69314718055994529 + 2.0 * (s * P)
+    with np.errstate(invalid='ignore'):
+        r = np.sqrt(-2.0 * lnu)
+    t = u2 * 8.0
+    k = t.astype(np.int64)                                # octant 0..7
+    f = t - k.astype(f8)
+    g = np.where((k & 1) == 1, 1.0 - f, f)
+    a = g * 0.78539816339744828
+    a2 = a * a
+    S = np.full_like(a, -1.0 / 355687428096000.0)
+    for sign, c in ((+1, 1307674368000.0), (-1, 6227020800.0), (+1, 39916800.0), (-1, 362880.0), (+1, 5040.0),
+                    (-1, 120.0), (+1, 6.0)):
+        S = S * a2 + 1.0 / c if sign > 0 else S * a2 - 1.0 / c
+    S = a - a * (a2 * S)
+    C = np.full_like(a, -1.0 / 6402373705728000.0)
+    for sign, c in ((+1, 20922789888000.0), (-1, 87178291200.0), (+1, 479001600.0), (-1, 3628800.0), (+1, 40320.0),
+                    (-1, 720.0), (+1, 24.0)):
+        C = C * a2 + 1.0 / c if sign > 0 else C * a2 - 1.0 / c
+    C = C * a2 - 0.5
+    C = C * a2 + 1.0
+    swap = (((k + 1) >> 1) & 1) == 1
+    c0, s0 = np.where(swap, S, C), np.where(swap, C, S)
+    z0 = r * np.where((((k + 2) >> 2) & 1) == 1, -c0, c0)
+    z1 = r * np.where(k >= 4, -s0, s0)
+    return z0, z1
+
+
+def device_normals(seed: int, step: int, env_ids, word: int):
+    """(z0, z1) for the global env ids `env_ids` at step counter `step` and stream word `word`:
+    Philox counter (env_lo, env_hi, step, word), key = (seed_lo, seed_hi)."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    B = env_ids.shape[0]
+    lo = (env_ids & _MASK).astype(np.uint32)
+    hi = (env_ids >> np.uint64(32)).astype(np.uint32)
+    k0 = np.full(B, seed & 0xFFFFFFFF, np.uint32)
+    k1 = np.full(B, (seed >> 32) & 0xFFFFFFFF, np.uint32)
+    w = philox4x32_10([lo, hi, np.full(B, step & 0xFFFFFFFF, np.uint32), np.full(B, word, np.uint32)], [k0, k1])
+    return normal_pair(w)
+
+
+def device_u_noise(spec: ScenarioSpec, seed: int, step: int, env_ids):
+    """[A, 2, B] standard normals the step kernels draw for u_noise (zeros for agents without one): pass as `noise`."""
+    out = np.zeros((spec.n_agents, 2, len(env_ids)))
+    for a in range(spec.n_agents):
+        if spec.u_noise[a]:
+            out[a, 0], out[a, 1] = device_normals(seed, step, env_ids, NOISE_WORD_U | a)
+    return out
+
+
+def device_c_noise(spec: ScenarioSpec, seed: int, step: int, env_ids):
+    """[A, dim_c, B] standard normals the step kernels draw for c_noise: pass as `cnoise`."""
+    out = np.zeros((spec.n_agents, spec.dim_c, len(env_ids)))
+    for a in range(spec.n_agents):
+        if spec.c_noise[a] and not spec.silent[a]:
+            for j in range((spec.dim_c + 1) // 2):
+                z0, z1 = device_normals(seed, step, env_ids, NOISE_WORD_C | (a << 8) | j)
+                out[a, 2 * j] = z0
+                if 2 * j + 1 < spec.dim_c:
+                    out[a, 2 * j + 1] = z1
+    return out

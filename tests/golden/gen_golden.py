@@ -271,6 +271,12 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
                 # env.force_discrete_action (environment.py:184-187): values on a coarse grid, so that ties occur and
                 # np.argmax's first-maximum rule matters
                 act = arng.randint(0, 4, size=(A, 5)) / 4.0
+            elif actions in ('continuous', 'continuous_force'):
+                # env.discrete_action_space = False (environment.py:191-192): the action IS u (dim_p = 2 entries), kept in
+                # columns 0, 1 of 'act'; 'continuous_force': values on a coarse grid (ties) + force_discrete_action
+                act = np.zeros((A, 5))
+                act[:, :2] = (arng.randint(-2, 3, size=(A, 2)) / 2.0 if actions == 'continuous_force'
+                              else arng.uniform(-1.0, 1.0, size=(A, 2)))
             else:
                 act = np.zeros((A, 5))
             s_t = 30_000 + 1000 * seed + t
@@ -279,6 +285,10 @@ def rollout(kind, seeds, T, scaled=None, u_noise=None, init=None, actions='rand'
             if actions == 'index':
                 env.discrete_action_input = True
                 obs_n, rew_n, done_n, info_n = env.step([int(act[i, 0]) for i in range(A)])
+            elif actions in ('continuous', 'continuous_force'):
+                env.discrete_action_space = False         # flipped after construction: the spaces stay Discrete(5)
+                env.force_discrete_action = actions == 'continuous_force'
+                obs_n, rew_n, done_n, info_n = env.step([act[i, :2].copy() for i in range(A)])   # scaled in place
             else:
                 env.force_discrete_action = actions == 'force'
                 obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in range(A)])
@@ -659,6 +669,15 @@ def discrete_cases():
     save('g16_simple_push_force_discrete', **rollout('simple_push', range(8), 25, init=dense_init, actions='force'))
     save('g16_h_S1L2F2_3Targets_100observe_force_discrete',
          **rollout_hier('S1L2F2_3Targets_100observe', range(8), 25, init=dense_init, force_discrete=True))
+    continuous_cases()
+
+
+def continuous_cases():
+    """env.discrete_action_space = False (environment.py:191-192, "NEVER do here" in the fork's comments but a live
+    switch): 'act'[:, :, :, 0:2] holds the force command u that was passed to env.step."""
+    save('g18_simple_tag_continuous', **rollout('simple_tag', range(16), 25, actions='continuous'))
+    save('g18_simple_spread_continuous', **rollout('simple_spread', range(8), 25, init=dense_init, actions='continuous'))
+    save('g18_simple_tag_continuous_force', **rollout('simple_tag', range(8), 25, actions='continuous_force'))
 
 
 def hier_rest():
@@ -672,6 +691,8 @@ if __name__ == '__main__':
         hier_rest()
     elif len(sys.argv) > 1 and sys.argv[1] == 'discrete':
         discrete_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'continuous':
+        continuous_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == 'scripted':
         scripted_cases()
     else:

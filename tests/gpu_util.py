@@ -70,20 +70,27 @@ class HipSim:
     def _p(self, t):
         return None if t is None else t.data_ptr()
 
-    def buffers(self, **kw):
-        """mpe_buffers with the state members set, plus the given tensors."""
-        return _hip.Buffers(flags=call_flags(), pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
+    def buffers(self, device_noise=None, **kw):
+        """mpe_buffers with the state members set, plus the given tensors.  device_noise = (seed, step, env_id0[,
+        int32 device tensor added to step]): MPE_FLAG_DEVICE_NOISE with those key words."""
+        b = _hip.Buffers(flags=call_flags(), pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
+        if device_noise is not None:
+            b.flags |= _hip.FLAG_DEVICE_NOISE
+            b.noise_seed, b.noise_step, b.env_id0 = device_noise[:3]
+            if len(device_noise) > 3 and device_noise[3] is not None:
+                b.noise_step_dev = device_noise[3].data_ptr()
+        return b
 
-    def env_step(self, act, noise=None, stats=None, want_info=True, comm=None, cnoise=None):
+    def env_step(self, act, noise=None, stats=None, want_info=True, comm=None, cnoise=None, device_noise=None):
         self._act, self._noise, self._cnoise = act, noise, cnoise   # keep alive until the stream has consumed them
-        b = self.buffers(act=act, noise=noise, comm=comm, cnoise=cnoise, obs=self.obs, rew=self.rew, stats=stats,
-                         info=self.info if (want_info and self.info.numel()) else None)
+        b = self.buffers(device_noise, act=act, noise=noise, comm=comm, cnoise=cnoise, obs=self.obs, rew=self.rew,
+                         stats=stats, info=self.info if (want_info and self.info.numel()) else None)
         rc = getattr(lib, 'mpe_env_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 
-    def world_step(self, act, noise=None, comm=None, cnoise=None):
+    def world_step(self, act, noise=None, comm=None, cnoise=None, device_noise=None):
         self._act, self._noise, self._cnoise = act, noise, cnoise
-        b = self.buffers(act=act, noise=noise, comm=comm, cnoise=cnoise)
+        b = self.buffers(device_noise, act=act, noise=noise, comm=comm, cnoise=cnoise)
         rc = getattr(lib, 'mpe_world_step_' + self.suf)(self.desc, self.B, self.ld, b, self.stream)
         assert rc == 0, lib.mpe_strerror(rc)
 

@@ -220,3 +220,99 @@ def test_force_discrete_on_multidiscrete_actions_matches_reference(golden_dir, f
             np.testing.assert_allclose(rew, golden_soa(g, 'rew', t), rtol=0, atol=1e-9)
     finally:
         set_call_flags(0)
+
+
+CONTINUOUS = [('g18_simple_tag_continuous', O.simple_tag_spec, False),
+              ('g18_simple_spread_continuous', O.simple_spread_spec, False),
+              ('g18_simple_tag_continuous_force', O.simple_tag_spec, True)]
+
+
+@pytest.mark.parametrize('name,mk,forced', CONTINUOUS)
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=['f64', 'f32'])
+def test_continuous_action_space_matches_reference_trajectories(golden_dir, name, mk, forced, dtype, tol):
+    """env.discrete_action_space = False (multiagent/environment.py:191-192): mpe_action_from_force_* writes the rows
+    (0, u_x, 0, u_y, 0) whose default decode is u, bit for bit; f64 free-running within 1e-9 of the reference's
+    trajectories, f32 teacher-forced within 1e-4."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    A = spec.n_agents
+    sim = HipSim(spec, S, dtype)
+    sim.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'))
+    for t in range(T):
+        if dtype == torch.float32 and t:
+            sim.set_state(golden_soa(g, 'pos', t - 1), golden_soa(g, 'vel', t - 1))
+        a = golden_soa(g, 'act', t)                                   # [A, 5, S]; columns 0, 1 = u
+        u = dev(np.ascontiguousarray(a[:, :2]), dtype)                # [A, 2, S]
+        act = torch.full((A * 5, S), float('nan'), dtype=dtype, device='cuda')
+        rc = getattr(lib, 'mpe_action_from_force_' + sim.suf)(sim.desc, S, S, S, u.data_ptr(), int(forced), act.data_ptr(),
+                                                              sim.stream)
+        assert rc == 0, lib.mpe_strerror(rc)
+        rows = act.double().cpu().numpy().reshape(A, 5, S)
+        want = a[:, :2].astype(np.float32 if dtype == torch.float32 else np.float64).astype(np.float64)
+        if forced:
+            second = np.argmax(a[:, :2], axis=1) == 1
+            want = np.stack([np.where(second, 0.0, 1.0), np.where(second, 1.0, 0.0)], 1)
+        assert np.array_equal(rows[:, 1], want[:, 0]) and np.array_equal(rows[:, 3], want[:, 1])
+        assert not rows[:, 0].any() and not rows[:, 2].any() and not rows[:, 4].any()
+        sim.env_step(act.view(A, 5, S))
+        pos, vel, obs, rew, info = sim.host()
+        np.testing.assert_allclose(pos, golden_soa(g, 'pos', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(vel, golden_soa(g, 'vel', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(obs, g['obs'][:, t].T, rtol=tol, atol=tol)
+        if dtype == torch.float64:
+            np.testing.assert_allclose(rew, golden_soa(g, 'rew', t), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize('name,mk,forced', CONTINUOUS)
+def test_env_api_continuous_action_space_matches_reference(golden_dir, name, mk, forced):
+    """The public switch, flipped after make_env like the reference's users must (the constructor hard-codes True,
+    environment.py:29): list of [B, 2] tensors, one [B, n, 2] tensor, numpy arrays."""
+    from marl_amd import make_env
+    g = _load(golden_dir, name)
+    S, T = g['act'].shape[:2]
+    env = make_env('simple_tag' if 'tag' in name else 'simple_spread', benchmark=False, num_envs=S, dtype=torch.float64, seed=1)
+    env.reset()
+    w = env.world
+    w.pos.copy_(dev(golden_soa(g, 'pos0'), torch.float64))
+    w.vel.copy_(dev(golden_soa(g, 'vel0'), torch.float64))
+    w.mark_dirty()
+    env.discrete_action_space = False
+    env.force_discrete_action = forced
+    for t in range(T):
+        u = g['act'][:, t, :, :2]                                      # [S, A, 2]
+        forms = [[dev(u[:, i], torch.float64) for i in range(env.n)], dev(u, torch.float64), [u[:, i].copy() for i in range(env.n)]]
+        passed = forms[t % 3]
+        obs_n, rew_n, done_n, info_n = env.step(passed)
+        if t % 3 == 0:                                                 # the caller's tensors are read, not scaled in place
+            assert all(torch.equal(p, dev(u[:, i], torch.float64)) for i, p in enumerate(passed))
+        np.testing.assert_allclose(w.pos.cpu().numpy(), golden_soa(g, 'pos', t), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(torch.cat(obs_n, 1).cpu().numpy(), g['obs'][:, t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(torch.stack(rew_n, 1).cpu().numpy(), g['rew'][:, t], rtol=0, atol=1e-9)
+
+
+def test_continuous_action_space_refused_for_movable_speaking_agents_and_bad_arguments():
+    from marl_amd import make_env
+    env = make_env('simple_reference', num_envs=8, dtype=torch.float64)
+    env.reset()
+    env.discrete_action_space = False
+    with pytest.raises(ValueError):                     # core.py:216 in the reference: 2-vector += 5-vector
+        env.step([torch.zeros(8, 2, dtype=torch.float64, device='cuda')] * 2)
+    ssim = HipSim(O.simple_world_comm_spec(), 64, torch.float64)
+    u = torch.zeros(6, 2, 64, dtype=torch.float64, device='cuda')
+    big = torch.zeros(6 * 9, 64, dtype=torch.float64, device='cuda')
+    f = lib.mpe_action_from_force_f64
+    assert f(ssim.desc, 64, 64, 64, u.data_ptr(), 0, big.data_ptr(), ssim.stream) == -5
+    sim = HipSim(O.simple_tag_spec(), 64, torch.float64)
+    act = torch.zeros(20, 64, dtype=torch.float64, device='cuda')
+    assert f(sim.desc, 64, 64, 64, None, 0, act.data_ptr(), sim.stream) == -1
+    assert f(sim.desc, 64, 64, 64, u.data_ptr(), 0, None, sim.stream) == -1
+    assert f(sim.desc, 64, 64, 32, u.data_ptr(), 0, act.data_ptr(), sim.stream) == -3
+    assert f(sim.desc, 64, 64, 64, u.data_ptr() + 4, 0, act.data_ptr(), sim.stream) == -4
+    # a speaker that cannot move has no physical rows: nothing is written for it, nothing is refused
+    sl = HipSim(O.speaker_listener_spec(), 64, torch.float64)
+    rows = torch.full((8, 64), 7.0, dtype=torch.float64, device='cuda')
+    u2 = torch.ones(2, 2, 64, dtype=torch.float64, device='cuda')
+    assert f(sl.desc, 64, 64, 64, u2.data_ptr(), 0, rows.data_ptr(), sl.stream) == 0
+    assert (rows[:3] == 7.0).all() and torch.equal(rows[3:, 0].cpu(), torch.tensor([0., 1., 0., 1., 0.], dtype=torch.float64))
+    torch.cuda.synchronize()

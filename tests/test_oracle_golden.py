@@ -575,6 +575,71 @@ def test_oracle_non_default_action_decodes_bit_exact(golden_dir, name, mk, mode)
         assert ((a == a.max(-1, keepdims=True)).sum(-1) > 1).any()      # ties: the first maximum decides
 
 
+CONTINUOUS_CASES = [('g18_simple_tag_continuous', O.simple_tag_spec, False),
+                    ('g18_simple_spread_continuous', O.simple_spread_spec, False),
+                    ('g18_simple_tag_continuous_force', O.simple_tag_spec, True)]
+
+
+@pytest.mark.parametrize('name,mk,forced', CONTINUOUS_CASES)
+def test_oracle_continuous_action_space_bit_exact(golden_dir, name, mk, forced):
+    """environment.py:191-192 (`env.discrete_action_space = False`, flipped after construction): the action is the
+    force command u itself (columns 0, 1 of the fixture's 'act'), times the sensitivity; with force_discrete_action
+    the argmax -> one-hot of :184-187 runs on the 2-vector first.  Serial and vectorised restatement against the
+    reference's trajectories."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    bo = O.BatchedOracle(spec, discrete_action_space=False, force_discrete_action=forced)
+    pos = np.ascontiguousarray(np.moveaxis(g['pos0'], 0, -1))
+    vel = np.ascontiguousarray(np.moveaxis(g['vel0'], 0, -1))
+    for t in range(T):
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, np.moveaxis(g['act'][:, t], 0, -1), None)
+        assert np.array_equal(pos, np.moveaxis(g['pos'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(vel, np.moveaxis(g['vel'][:, t], 0, -1)), (name, t)
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T), (name, t)
+        assert np.array_equal(rew, g['rew'][:, t].T), (name, t)
+    for s in range(min(S, 4)):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.discrete_action_space = False
+        env.force_discrete_action = forced
+        env.set_state(g['pos0'][s], g['vel0'][s])
+        for t in range(T):
+            obs_n, rew_n, _, _ = env.step([a[:2].copy() for a in g['act'][s, t]])
+            p, v = env.get_state()
+            assert np.array_equal(p, g['pos'][s, t]) and np.array_equal(v, g['vel'][s, t]), (name, s, t)
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t]), (name, s, t)
+    if forced:
+        u = g['act'][..., :2]
+        assert (u[..., 0] == u[..., 1]).any()                           # ties: the first maximum decides
+
+
+def test_device_normals_are_standard_normal_and_keyed_by_global_env_id():
+    """The in-kernel u_noise / c_noise draw (MPE_FLAG_DEVICE_NOISE; restated in oracle.device_normals): moments of a
+    standard normal, agreement with libm's log / sin / cos to ~1e-15, and a draw that depends on (seed, env id, step,
+    word) only -- a shard of a batch draws the unsharded batch's numbers."""
+    ids = np.arange(400_000, dtype=np.uint64)
+    z0, z1 = O.device_normals(11, 5, ids, O.NOISE_WORD_U | 2)
+    z = np.concatenate([z0, z1])
+    assert np.isfinite(z).all() and abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+    assert abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3) < 5e-2 and abs(np.corrcoef(z0, z1)[0, 1]) < 5e-3
+    lo = (ids & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    w = O.philox4x32_10([lo, np.zeros_like(lo), np.full_like(lo, 5), np.full_like(lo, O.NOISE_WORD_U | 2)],
+                        [np.full_like(lo, 11), np.zeros_like(lo)])
+    u1 = ((w[0] >> np.uint32(5)).astype(float) * 67108864.0 + (w[1] >> np.uint32(6)).astype(float) + 1.0) * 2.0 ** -53
+    u2 = ((w[2] >> np.uint32(5)).astype(float) * 67108864.0 + (w[3] >> np.uint32(6)).astype(float)) * 2.0 ** -53
+    r = np.sqrt(-2 * np.log(u1))
+    assert np.abs(z0 - r * np.cos(2 * np.pi * u2)).max() < 1e-13 and np.abs(z1 - r * np.sin(2 * np.pi * u2)).max() < 1e-13
+    a0, a1 = O.device_normals(11, 5, ids[1000:2000], O.NOISE_WORD_U | 2)
+    assert np.array_equal(a0, z0[1000:2000]) and np.array_equal(a1, z1[1000:2000])
+    b0, _ = O.device_normals(11, 6, ids[:1000], O.NOISE_WORD_U | 2)
+    c0, _ = O.device_normals(12, 5, ids[:1000], O.NOISE_WORD_U | 2)
+    d0, _ = O.device_normals(11, 5, ids[:1000], O.NOISE_WORD_U | 3)
+    assert not np.array_equal(b0, z0[:1000]) and not np.array_equal(c0, z0[:1000]) and not np.array_equal(d0, z0[:1000])
+    spec = O.simple_tag_spec(u_noise=0.3)
+    n = O.device_u_noise(spec, 11, 5, ids[:64])
+    assert n.shape == (4, 2, 64) and np.array_equal(n[2, 0], z0[:64]) and np.array_equal(n[2, 1], z1[:64])
+
+
 def scripted_callbacks(name):
     """The callbacks of tests/golden/gen_golden.py:SCRIPTED restated on (pos [E, 2, ...], agent index) -> u [2, ...]: capped
     proportional controllers towards an entity."""
