@@ -276,7 +276,7 @@ def test_silent_comm_zero_flag_leaves_silent_rows_alone(golden_dir, name, flags,
             assert torch.equal(c0[i], c1[i]) and not (c0[i] == 7.5).all(), i
     for x, y in zip(rest0, rest1):
         assert (x is None and y is None) or torch.equal(x.nan_to_num(nan=123.0), y.nan_to_num(nan=123.0))
-    assert lib.mpe_stats_rows(sim.desc, S, 4, 16) == -6          # an unknown flag bit: MPE_ERR_ARG
+    assert lib.mpe_stats_rows(sim.desc, S, 4, 32) == -6          # an unknown flag bit: MPE_ERR_ARG
 
 
 def test_world_keeps_silent_comm_rows_zero_without_rewriting_them():

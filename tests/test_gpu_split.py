@@ -81,7 +81,7 @@ def test_default_selection_by_batch_size():
     assert rows(tag, n, 0) == n // 64 and rows(tag, n + 1, 0) == -(-(n + 1) // 256)
     assert rows(tag, 1 << 20, SPLIT) == (1 << 20) // 64 and rows(tag, 4096, WIDE) == 16
     assert rows(adv, 4096, 0) == rows(adv, 4096, SPLIT) == rows(adv, 4096, WIDE) == 16
-    assert rows(tag, 4096, 16) < 0                              # unknown flag bit
+    assert rows(tag, 4096, 32) < 0                              # unknown flag bit
 
 
 @pytest.mark.parametrize('scenario', ['simple_tag', 'simple_spread'])
