@@ -18,6 +18,11 @@
 
 namespace mpe {
 
+#ifndef MPE_HIER_LDS_TARGETS
+#define MPE_HIER_LDS_TARGETS 10
+#endif
+constexpr int kHierLdsTargets = MPE_HIER_LDS_TARGETS;  // worlds with at least this many targets keep them in LDS
+
 // Occupancy cap, see mpe_small_kernel.h (L1F2_3Targets f32: 94.2 us uncapped at 5 waves/SIMD, 84.5 us at 3)
 #ifndef MPE_HIER_ATTR
 #define MPE_HIER_ATTR __attribute__((amdgpu_waves_per_eu(1, 3)))
@@ -27,9 +32,13 @@ namespace mpe {
 // pair forces, integration, comm / leader_force write-back; or, when only observing, the leader_force load.
 // Agent order: NF silent followers, then the speaking leaders, then NG silent good agents (the prey of the
 // *_MovingTarget files; 0 in the Targets files).
-template <typename T, int A, int E, int NF, int NG, int C, bool DO_STEP, bool DO_OBS>
-__device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk0, const uint32_t lo, T (&px)[E], T (&py)[E],
-                                          T (&vx)[A], T (&vy)[A], T (&lfx)[A], T (&lfy)[A]) {
+//
+// EREG: how many entity positions sit in the px / py registers: all E, or only the A agents when the targets are kept in
+// LDS (hier_kernel, L >= kHierLdsTargets); then tgt(l, component) reads target l of this lane's env.
+template <typename T, int A, int E, int NF, int NG, int C, bool DO_STEP, bool DO_OBS, int EREG, typename TgtFn>
+__device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk0, const uint32_t lo, T (&px)[EREG],
+                                          T (&py)[EREG], T (&vx)[A], T (&vy)[A], T (&lfx)[A], T (&lfy)[A], TgtFn tgt) {
+  static_assert(EREG == E || EREG == A, "all entities in registers, or the agents only");
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
@@ -123,11 +132,26 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
 #pragma unroll
     for (int a = 0; a < A; ++a) {  // core.py:199-205, b ascending; only a is pushed
 #pragma unroll
-      for (int b = a + 1; b < E; ++b) {
+      for (int b = a + 1; b < EREG; ++b) {
         T fx, fy;
         pair_force<T>(px[a] - px[b], py[a] - py[b], d.size[a] + d.size[b], d, fx, fy);
         Fx[a] = fx + Fx[a];
         Fy[a] = fy + Fy[a];
+      }
+    }
+    if constexpr (EREG < E) {
+      // the targets, one at a time out of LDS: every agent's sum still grows in ascending b (its agent pairs above, then
+      // the targets in order), and the A pair forces of one target are independent instruction streams
+#pragma unroll
+      for (int b = A; b < E; ++b) {
+        const T bx = tgt(b - A, 0), by = tgt(b - A, 1);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          T fx, fy;
+          pair_force<T>(px[a] - bx, py[a] - by, d.size[a] + d.size[b], d, fx, fy);
+          Fx[a] = fx + Fx[a];
+          Fy[a] = fy + Fy[a];
+        }
       }
     }
     const Win<T> wlf(p.lforce + blk0, ld);
@@ -175,12 +199,23 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
   const bool active = blk0 + threadIdx.x < p.B;
   const uint32_t lo = active ? threadIdx.x : kNoLane;  // tail lanes: see Win
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
-  T px[E], py[E], vx[A], vy[A], lfx[A], lfy[A];
+  // Ten-target worlds keep the (immovable) targets in LDS, column = lane: nobody but the lane itself touches its column,
+  // so there is no barrier.  20 fewer position registers (40 in f64), and the three nearest targets are fetched by
+  // INDEX after the selection passes instead of being dragged through them as two more selects per candidate.
+  constexpr bool TLDS = L >= kHierLdsTargets;
+  constexpr int EREG = TLDS ? A : E;
+  __shared__ T sT[TLDS ? 2 * L : 1][TLDS ? THREADS : 1];
+  T px[EREG], py[EREG], vx[A], vy[A], lfx[A], lfy[A];
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
+  for (int e = 0; e < EREG; ++e) {
     px[e] = wpos.ld_state(2 * e, lo);
     py[e] = wpos.ld_state(2 * e + 1, lo);
   }
+  if constexpr (TLDS) {
+#pragma unroll
+    for (int r = 0; r < 2 * L; ++r) sT[r][threadIdx.x] = wpos.ld_state(2 * A + r, lo);
+  }
+  auto tgt = [&](int l, int c) -> T { return sT[TLDS ? 2 * l + c : 0][TLDS ? threadIdx.x : 0]; };
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     vx[a] = wvel.ld_state(2 * a, lo);
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
     lfx[a] = lfy[a] = T(0);
   }
 
-  hier_step<T, A, E, NF, 0, C, DO_STEP, DO_OBS>(p, blk0, lo, px, py, vx, vy, lfx, lfy);
+  hier_step<T, A, E, NF, 0, C, DO_STEP, DO_OBS, EREG>(p, blk0, lo, px, py, vx, vy, lfx, lfy, tgt);
 
   if (DO_OBS) {
     const bool want_obs = p.obs != nullptr, want_rew = p.rew != nullptr, want_info = p.info != nullptr,
@@ -197,17 +232,45 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
     // ---- observations (:196-253) and the per-agent target contacts, one agent at a time -------------
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-      T tdx[L], tdy[L], td2[L];
+      T tdx[TLDS ? 1 : L], tdy[TLDS ? 1 : L], td2[TLDS ? 1 : L];
       int n = 0;
+      // TLDS: the NT nearest visible targets are kept as a sorted (d2, index) list while the targets stream by, in index
+      // order with strict comparisons: a tie leaves the earlier index in front, like the reference's stable sort.
+      // 20 instructions per target instead of 36 for three selection passes, and no td2[] array.
+      const T r2 = d.obs_r2[i];
+      T bd[NT];
+      int bl[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        bd[k] = T(0);
+        bl[k] = -1;  // empty slot: anything visible goes in front of it
+      }
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        tdx[l] = px[A + l] - px[i];
-        tdy[l] = py[A + l] - py[i];
-        td2[l] = tdx[l] * tdx[l] + tdy[l] * tdy[l];
+        T dx, dy, d2;
+        if constexpr (TLDS) {
+          dx = tgt(l, 0) - px[i];
+          dy = tgt(l, 1) - py[i];
+          d2 = dx * dx + dy * dy;
+          const bool seen = d2 < r2;
+          bool in[NT];  // goes in front of slot k
+#pragma unroll
+          for (int k = 0; k < NT; ++k) in[k] = seen && (bl[k] < 0 || d2 < bd[k]);
+#pragma unroll
+          for (int k = NT - 1; k >= 0; --k) {
+            const bool shift = k > 0 && in[k - 1];  // the new one lands further in front: slot k takes slot k - 1
+            bd[k] = shift ? bd[k - 1] : (in[k] ? d2 : bd[k]);
+            bl[k] = shift ? bl[k - 1] : (in[k] ? l : bl[k]);
+          }
+        } else {
+          dx = tdx[l] = px[A + l] - px[i];
+          dy = tdy[l] = py[A + l] - py[i];
+          d2 = td2[l] = dx * dx + dy * dy;
+        }
 #ifdef MPE_HIER_SQRT_CONTACT
-        n += t_sqrt<T>(td2[l]) < d.size[A + l] + d.size[i] ? 1 : 0;
+        n += t_sqrt<T>(d2) < d.size[A + l] + d.size[i] ? 1 : 0;
 #else
-        n += touching_d2<T>(td2[l], d.size[A + l] + d.size[i]) ? 1 : 0;
+        n += touching_d2<T>(d2, d.size[A + l] + d.size[i]) ? 1 : 0;
 #endif
       }
       hits[i] = n;
@@ -218,7 +281,6 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       wobs.st_stream(r++, lo, vy[i]);
       wobs.st_stream(r++, lo, px[i]);
       wobs.st_stream(r++, lo, py[i]);
-      const T r2 = d.obs_r2[i];
       const int fi = d.force_id[i], fdi = d.forced_id[i];
       bool vis[A];
 #pragma unroll
@@ -240,28 +302,37 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         wobs.st_stream(r++, lo, lfx[i]);
         wobs.st_stream(r++, lo, lfy[i]);
       }
-      // visible targets, nearest first, ties by index (stable sort, :242-245), then zeros.  (A single pass that keeps
-      // the three best was tried in round 2: same time in f32, and in f64 its nine extra live doubles push the 10-target
-      // kernel from 225 to 274 VGPRs = one wavefront per SIMD, 673 -> 1 035 us.)
+      // visible targets, nearest first, ties by index (stable sort, :242-245), then zeros.  Three-target worlds: three
+      // selection passes over registers.  (Round 2 tried the single pass there, with the relative positions carried
+      // along: nine extra live doubles, 225 -> 274 VGPRs in f64.  With the targets in LDS the list holds (d2, index)
+      // only and the positions are fetched afterwards.)
       T prev_d = T(0);
       int prev_l = -1;
 #pragma unroll
       for (int k = 0; k < NT; ++k) {
-        int best_l = -1;
-        T best_d = T(0), bx = T(0), by = T(0);
+        T bx = T(0), by = T(0);
+        if constexpr (TLDS) {  // the k-th nearest's relative position: the same subtraction as above, fetched by index
+          const int l = bl[k] < 0 ? 0 : bl[k];
+          const T tx = sT[2 * l][threadIdx.x] - px[i], ty = sT[2 * l + 1][threadIdx.x] - py[i];
+          bx = bl[k] < 0 ? T(0) : tx;
+          by = bl[k] < 0 ? T(0) : ty;
+        } else {
+          int best_l = -1;
+          T best_d = T(0);
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-          // k == 0: nothing chosen yet.  Later slots: strictly after the previous pick in (d2, index)
-          // order; once a slot finds nothing (best_l = -1 -> prev_l = L) the rest find nothing either.
-          const bool after = k == 0 || td2[l] > prev_d || (td2[l] == prev_d && l > prev_l);
-          const bool take = td2[l] < r2 && after && (best_l < 0 || td2[l] < best_d);
-          best_l = take ? l : best_l;
-          best_d = take ? td2[l] : best_d;
-          bx = take ? tdx[l] : bx;
-          by = take ? tdy[l] : by;
+          for (int l = 0; l < L; ++l) {
+            // k == 0: nothing chosen yet.  Later slots: strictly after the previous pick in (d2, index)
+            // order; once a slot finds nothing (best_l = -1 -> prev_l = L) the rest find nothing either.
+            const bool after = k == 0 || td2[l] > prev_d || (td2[l] == prev_d && l > prev_l);
+            const bool take = td2[l] < r2 && after && (best_l < 0 || td2[l] < best_d);
+            best_l = take ? l : best_l;
+            best_d = take ? td2[l] : best_d;
+            bx = take ? tdx[l] : bx;
+            by = take ? tdy[l] : by;
+          }
+          prev_d = best_l < 0 ? r2 : best_d;  // nothing found: no later d2 < r2 can follow
+          prev_l = best_l < 0 ? L : best_l;
         }
-        prev_d = best_l < 0 ? r2 : best_d;  // nothing found: no later d2 < r2 can follow
-        prev_l = best_l < 0 ? L : best_l;
         wobs.st_stream(r++, lo, bx);
         wobs.st_stream(r++, lo, by);
       }
@@ -355,8 +426,11 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
 #ifndef MPE_MOVING_CAP
 #define MPE_MOVING_CAP 2  // S1L2F4_MovingTarget 1Mi f32: 388.8 us at 3, 376.0 at 2, 387.5 at 4 (477 rows per wavefront)
 #endif
+#ifndef MPE_MOVING_ATTR
+#define MPE_MOVING_ATTR __attribute__((amdgpu_waves_per_eu(1, MPE_MOVING_CAP)))
+#endif
 template <typename T, int A, int NF, int C, int THREADS, bool DO_STEP, bool DO_OBS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_MOVING_CAP))) void moving_kernel(const KParams<T> p) {
+__global__ __launch_bounds__(THREADS) MPE_MOVING_ATTR void moving_kernel(const KParams<T> p) {
   constexpr int E = A, G = A - 1;  // G: the prey
   const DevDesc<T> &d = p.d;
   const int64_t ld = p.ld;
@@ -376,11 +450,29 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
     vy[a] = wvel.ld_state(2 * a + 1, lo);
     lfx[a] = lfy[a] = T(0);
   }
-  hier_step<T, A, E, NF, 1, C, DO_STEP, DO_OBS>(p, blk0, lo, px, py, vx, vy, lfx, lfy);
+  hier_step<T, A, E, NF, 1, C, DO_STEP, DO_OBS, E>(p, blk0, lo, px, py, vx, vy, lfx, lfy, [](int, int) { return T(0); });
 
   if (DO_OBS) {
     const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;
     if (p.obs != nullptr) {
+      // who is inside whose radius (:233-236: np.sqrt(np.sum(np.square(delta))) < agent.obs_r): the distance of a pair
+      // is the same from both ends ((-dx)^2 == dx^2 exactly), so each unordered pair is measured once and tested
+      // against both radii; touching_d2 is that very comparison (f64: decided on the squares outside a 2^-50 band
+      // around the radius, the reference's square root inside it).  Bit (8 i + j): j is within i's radius.
+      static_assert(A <= 8, "visibility bits: 8 x 8");
+      uint64_t near = 0;
+#ifndef MPE_MOVING_SQRT_VIS
+#pragma unroll
+      for (int i = 0; i < A; ++i) {
+#pragma unroll
+        for (int j = i + 1; j < A; ++j) {
+          const T dx = px[j] - px[i], dy = py[j] - py[i];
+          const T d2 = dx * dx + dy * dy;
+          if (i != G) near |= (uint64_t)touching_d2<T>(d2, d.obs_r[i]) << (8 * i + j);
+          if (j != G) near |= (uint64_t)touching_d2<T>(d2, d.obs_r[j]) << (8 * j + i);
+        }
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < A; ++i) {  // L1F4_MovingTarget.py:214-258
         const Win<T> wobs(p.obs + blk0 + (int64_t)d.obs_row0[i] * ld, ld);
@@ -389,7 +481,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
         wobs.st_stream(r++, lo, vy[i]);
         wobs.st_stream(r++, lo, px[i]);
         wobs.st_stream(r++, lo, py[i]);
-        const T rad = d.obs_r[i];
         const int fi = d.force_id[i], fdi = d.forced_id[i];
         bool vis[A];
 #pragma unroll
@@ -398,7 +489,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
           const T dx = px[j] - px[i], dy = py[j] - py[i];
           const bool linked = d.reward_variant == 0 &&
                               ((fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]));
-          vis[j] = i == G || linked || t_sqrt<T>(dx * dx + dy * dy) < rad;
+#ifndef MPE_MOVING_SQRT_VIS
+          vis[j] = i == G || linked || ((near >> (8 * i + j)) & 1);
+#else
+          vis[j] = i == G || linked || t_sqrt<T>(dx * dx + dy * dy) < d.obs_r[i];
+#endif
           wobs.st_stream(r++, lo, i == G ? px[j] : (vis[j] ? dx : T(0)));  // the prey: absolute (:249-251)
           wobs.st_stream(r++, lo, i == G ? py[j] : (vis[j] ? dy : T(0)));
         }
