@@ -59,6 +59,43 @@ __device__ __forceinline__ void st_stream_vec(T *ptr, typename Vec16<T>::type v,
 // trip: lane (r, q) handles row b0 + r, envs VEC q .. VEC q + VEC - 1, so one store instruction writes four 256-byte
 // row segments and one ds_read_b128 per lane fetches them (1 KiB of LDS per wave-instruction, conflict-free).
 // Sections start on even rows and b0 is a multiple of 4, so row parity (x / y) is r & 1 throughout.
+// 16 bytes (the lane's VEC consecutive envs) of one source row: LDS rows and, with FULL, global rows are aligned.
+template <typename T, bool FULL>
+__device__ __forceinline__ typename Vec16<T>::type ld_vec(const T *ptr, int nvalid) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VEC = 16 / sizeof(T);
+  if (FULL) return *reinterpret_cast<const VT *>(ptr);
+  VT v;
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) v[c] = c < nvalid ? ptr[c] : T(0);
+  return v;
+}
+
+// The landmark section of an agent's observation with the landmark rows read from GLOBAL memory (LGLOB tiles keep only
+// the agents in LDS): row kk of the section is position row 2A + kk of the SoA array; `lane_src` points at (row 2A + r,
+// this lane's first env).  Same lane mapping as obs_section: four rows per store instruction.
+template <typename T, bool FULL>
+__device__ __forceinline__ void obs_section_global(T *lane_out, int64_t ld, const T *lane_src, int nrows, int r,
+                                                   typename Vec16<T>::type pi, int nvalid) {
+  typedef typename Vec16<T>::type VT;
+  int b0 = 0;
+  for (; b0 + 4 < nrows; b0 += 8) {  // two blocks per trip: both loads are in flight before the first subtraction
+    const bool ok1 = b0 + 4 + r < nrows;
+    VT v0 = ld_vec<T, FULL>(lane_src + (int64_t)b0 * ld, nvalid);
+    VT v1 = ld_vec<T, FULL>(lane_src + (int64_t)(ok1 ? b0 + 4 : 0) * ld, nvalid);
+    v0 = v0 - pi;
+    v1 = v1 - pi;
+    st_stream_vec<T>(lane_out + (int64_t)b0 * ld, v0, nvalid, FULL);
+    if (ok1) st_stream_vec<T>(lane_out + (int64_t)(b0 + 4) * ld, v1, nvalid, FULL);
+  }
+  if (b0 < nrows) {
+    const bool ok = b0 + r < nrows;
+    VT v = ld_vec<T, FULL>(lane_src + (int64_t)(ok ? b0 : 0) * ld, nvalid);
+    v = v - pi;
+    if (ok) st_stream_vec<T>(lane_out + (int64_t)b0 * ld, v, nvalid, FULL);
+  }
+}
+
 template <typename T, int TILE, bool REL, bool FULL>
 __device__ __forceinline__ void obs_section(T *lane_out, int64_t ld, const T *lane_src, int nrows, int skip, int r,
                                             typename Vec16<T>::type pi, int nvalid) {
@@ -90,7 +127,10 @@ __device__ __forceinline__ void obs_section(T *lane_out, int64_t ld, const T *la
 // agents: [vel_i, pos_i, landmarks - pos_i, other agents - pos_i, (tag) velocities of the other good agents /
 // (spread) dim_c (A-1) zeros].  Wavefront w takes agents w, w + NW, ...; 94 % of the scaled world's HBM traffic is
 // issued here, as 16-byte stores (global_store_dwordx4), 4 rows per instruction.
-template <typename T, int TILE, int THREADS, bool TAG, bool FULL>
+//
+// LGLOB: the tile keeps only the agents' positions and the good agents' velocities in LDS (sVel row pair g = the g-th good
+// agent); landmark rows come from global memory, and every agent's own velocity rows were already stored by phase 1.
+template <typename T, int TILE, int THREADS, bool TAG, bool FULL, bool LGLOB>
 __device__ __forceinline__ void obs_rows_vec_impl(const KParams<T> &p, const T *sPos, const T *sVel, int64_t tile) {
   constexpr int VEC = 16 / sizeof(T);
   static_assert(TILE == 16 * VEC, "a row segment of the tile is 16 lanes x 16 bytes");
@@ -108,12 +148,16 @@ __device__ __forceinline__ void obs_rows_vec_impl(const KParams<T> &p, const T *
   for (int i = wv; i < A; i += NW) {
     T *o = p.obs + (int64_t)(d.obs_row0[i] + r) * ld + env0;  // this lane's row of block 0
     const VT pi = *reinterpret_cast<const VT *>(sPos + (2 * i + (r & 1)) * TILE + lcol);
-    {  // [vel_i, pos_i]
+    if constexpr (LGLOB) {  // [vel_i (stored by phase 1), pos_i]
+      if (r >= 2) st_stream_vec<T>(o, pi, nvalid, FULL);
+      o += 4 * ld;
+      obs_section_global<T, FULL>(o, ld, p.pos + (int64_t)(2 * A + r) * ld + env0, 2 * L, r, pi, nvalid);
+    } else {  // [vel_i, pos_i]
       const T *s0 = (r < 2 ? sVel : sPos) + (2 * i + (r & 1)) * TILE + lcol;
       st_stream_vec<T>(o, *reinterpret_cast<const VT *>(s0), nvalid, FULL);
       o += 4 * ld;
+      obs_section<T, TILE, true, FULL>(o, ld, sPos + (2 * A + r) * TILE + lcol, 2 * L, 0x7fffffff, r, pi, nvalid);
     }
-    obs_section<T, TILE, true, FULL>(o, ld, sPos + (2 * A + r) * TILE + lcol, 2 * L, 0x7fffffff, r, pi, nvalid);
     o += (int64_t)(2 * L) * ld;
     obs_section<T, TILE, true, FULL>(o, ld, sPos + r * TILE + lcol, 2 * (A - 1), 2 * i, r, pi, nvalid);
     o += (int64_t)(2 * (A - 1)) * ld;
@@ -130,8 +174,10 @@ __device__ __forceinline__ void obs_rows_vec_impl(const KParams<T> &p, const T *
       const int nrows = 2 * (d.n_good - (i_good ? 1 : 0));
       for (int b0 = 0; b0 < nrows; b0 += 4) {
         const int ga = b0 >> 1, gb = ga + 1;
-        const int ja = d.good_list[ga + (ga >= rank ? 1 : 0)];
-        const int jb = 2 * gb < nrows ? d.good_list[gb + (gb >= rank ? 1 : 0)] : ja;
+        // LGLOB: the velocity rows in LDS are indexed by position in the good list, not by agent
+        const int sa = ga + (ga >= rank ? 1 : 0), sb = gb + (gb >= rank ? 1 : 0);
+        const int ja = LGLOB ? sa : d.good_list[sa];
+        const int jb = 2 * gb < nrows ? (LGLOB ? sb : d.good_list[sb]) : ja;
         const bool ok = b0 + r < nrows;
         const VT v = *reinterpret_cast<const VT *>(sVel + (2 * (r >> 1 ? jb : ja) + (r & 1)) * TILE + lcol);
         if (ok) st_stream_vec<T>(o + (int64_t)b0 * ld, v, nvalid, FULL);
@@ -147,13 +193,14 @@ __device__ __forceinline__ void obs_rows_vec_impl(const KParams<T> &p, const T *
   }
 }
 
-template <typename T, int TILE, int THREADS, bool TAG>
+template <typename T, int TILE, int THREADS, bool TAG, bool LGLOB>
 __device__ __forceinline__ void obs_rows_vec(const KParams<T> &p, const T *sPos, const T *sVel, int64_t tile) {
   constexpr int VEC = 16 / sizeof(T);
-  // whole 16-byte stores everywhere (workgroup-uniform test): every env of the tile exists, rows and base are aligned
-  const bool full = (tile + 1) * TILE <= p.B && (p.ld % VEC) == 0 && (reinterpret_cast<uintptr_t>(p.obs) % 16) == 0;
-  if (full) obs_rows_vec_impl<T, TILE, THREADS, TAG, true>(p, sPos, sVel, tile);
-  else obs_rows_vec_impl<T, TILE, THREADS, TAG, false>(p, sPos, sVel, tile);
+  // whole 16-byte accesses everywhere (workgroup-uniform test): every env of the tile exists, rows and bases are aligned
+  const bool full = (tile + 1) * TILE <= p.B && (p.ld % VEC) == 0 && (reinterpret_cast<uintptr_t>(p.obs) % 16) == 0 &&
+                    (!LGLOB || (reinterpret_cast<uintptr_t>(p.pos) % 16) == 0);
+  if (full) obs_rows_vec_impl<T, TILE, THREADS, TAG, true, LGLOB>(p, sPos, sVel, tile);
+  else obs_rows_vec_impl<T, TILE, THREADS, TAG, false, LGLOB>(p, sPos, sVel, tile);
 }
 
 // HIER: the world may carry ragged actions / speaking agents (kinds MPE_HIER_PURSUIT, the only one with
@@ -163,16 +210,40 @@ __device__ __forceinline__ void obs_rows_vec(const KParams<T> &p, const T *sPos,
 // KIND: MPE_SIMPLE_TAG / MPE_SIMPLE_SPREAD compile the scenario in (the north-star worlds at any size: the other
 // kinds' branches disappear, and with them most of the live scalars: the all-kinds build of the scaled simple_tag
 // step needed 106 SGPRs + 134 spilled to VGPR lanes); -1 = the kind is read from the descriptor at run time.
-template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER, int KIND>
-__global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
+//
+// LGLOB (the fused step of the specialised simple_tag kind only): the landmarks stay in global memory.
+// They never move and 94 % of this kernel's time is the observation store stream, whose rate depends on how many
+// workgroups per CU are at a different point of their tile (load -> forces -> stores); LDS is what limits that number.
+//   LDS:  sPos[2A][TILE] (agents only)  sVel[2 n_good][TILE] (the good agents' velocities, by position in the good
+//         list)  -- E = 96 / A = 64 / 16 good: 40 KiB instead of 80 = 4 workgroups per CU
+//   phase 1 reads landmark rows with coalesced global loads (L2 hits after the first chunk), stores the new velocity,
+//           the new POSITION and the agent's own two velocity rows of its observation straight from registers;
+//   phase 2 reloads the new positions of the chunk's agents into LDS (same thread, same addresses) once every pair
+//           loop is done with the old ones;
+//   phase 3 reads the landmark section of every observation from global memory (16 bytes per lane, four rows per
+//           instruction as before); the reward scratch is 4 adversaries per int (counts <= n_good <= 64).
+// Same arithmetic in the same order as the LDS form: bit-identical (tests/test_gpu_parity.py).
+// Register budget.  The LGLOB form is compiled for 6 wavefronts per SIMD (80 VGPRs instead of the 111 the compiler takes
+// when left alone): 24 wavefronts per CU = three 512-thread workgroups of 40 KiB.  Measured on the scaled world (r3,
+// profiles/r3_tile_lglob.txt): LDS form 3.33 ms; LGLOB at 4 x 256 threads 3.41, at 2 x 512 (111 VGPRs) 3.18 vs 3.21 on
+// another box, at 3 x 512 (this) 3.27 (2.98 on the other box), forced to 7 / 8 wavefronts (spills) 3.30 / 3.31.
+constexpr int tile_min_waves(bool lglob) { return lglob ? 6 : 1; }
+constexpr int tile_max_waves(bool lglob) { return lglob ? 6 : 8; }
+#ifndef MPE_TILE_ATTR
+#define MPE_TILE_ATTR __attribute__((amdgpu_waves_per_eu(tile_min_waves(LGLOB), tile_max_waves(LGLOB))))
+#endif
+template <typename T, int TILE, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER, int KIND, bool LGLOB = false>
+__global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KParams<T> p) {
   constexpr int NCH = THREADS / TILE;
   static_assert(!HIER || KIND < 0, "the ragged kinds are not specialised");
+  static_assert(!LGLOB || (DO_STEP && DO_OBS && KIND == MPE_SIMPLE_TAG),
+                "landmarks in global memory: the fused simple_tag step only");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const DevDesc<T> &d = p.d;
   const int kind = KIND >= 0 ? KIND : d.kind;
   const int A = d.A, L = d.L, E = d.E;
   T *sPos = reinterpret_cast<T *>(smem_raw);
-  T *sLf = sPos + 2 * E * TILE;
+  T *sLf = sPos + 2 * (LGLOB ? A : E) * TILE;
   const bool has_lf = HIER && d.has_lforce;
   T *sVel = sLf + (has_lf ? 2 * A * TILE : 0);
   T *sAux = sVel;  // valid only after the observation phase
@@ -193,7 +264,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
     const int64_t ge = active ? env : (p.B - 1);  // inactive lanes shadow the last env, never store
 
     // ---- phase 0 ------------------------------------------------------------------------------
-    for (int r = chunk; r < 2 * E; r += NCH) sPos[r * TILE + lane] = ld_state(p.pos + (int64_t)r * ld + ge);
+    for (int r = chunk; r < 2 * (LGLOB ? A : E); r += NCH) sPos[r * TILE + lane] = ld_state(p.pos + (int64_t)r * ld + ge);
     // Inputs of one agent of one env: old velocity, the four action entries that matter, u_noise normals.  Fetched one
     // agent ahead of the pair loop (and the first one here, beside the position loads), so that the HBM latency of
     // these read-once rows -- several microseconds while the chip streams observations -- hides behind compute.
@@ -262,40 +333,53 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
             const T pax = sPos[(2 * a) * TILE + lane], pay = sPos[(2 * a + 1) * TILE + lane];
             const T sa = d.size[a];
             int b = a + 1;
-            if (d.ncol_prefix >= 0) {
-              // regular worlds (all of [0, ncol) collide): U independent pair evaluations per trip
-              // for instruction-level parallelism; the additions stay in ascending-b order.
-#ifdef MPE_ABL_NO_PAIRS
-              const int bend = b + 1 < d.ncol_prefix ? b + 1 : d.ncol_prefix;
-#else
-              const int bend = d.ncol_prefix;
-#endif
+            // positions of entity b: LDS; with LGLOB the landmarks (b >= A) come from global memory
+            auto bx_lds = [&](int e) { return sPos[(2 * e) * TILE + lane]; };
+            auto by_lds = [&](int e) { return sPos[(2 * e + 1) * TILE + lane]; };
+            auto bx_glb = [&](int e) { return ld_state(p.pos + (int64_t)(2 * e) * ld + ge); };
+            auto by_glb = [&](int e) { return ld_state(p.pos + (int64_t)(2 * e + 1) * ld + ge); };
+            // regular worlds (all of [0, ncol) collide): U independent pair evaluations per trip for
+            // instruction-level parallelism; the additions stay in ascending-b order.
+            auto run = [&](int b0, int b1, auto bx, auto by) {
               constexpr int U = sizeof(T) == 4 ? 4 : 1;  // f64 pair code is long: unrolling it spills
-              for (; b + U - 1 < bend; b += U) {
+              int q = b0;
+              for (; q + U - 1 < b1; q += U) {
                 T fx[U], fy[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                  pair_force<T>(pax - sPos[(2 * (b + u)) * TILE + lane], pay - sPos[(2 * (b + u) + 1) * TILE + lane],
-                                sa + d.size[b + u], d, fx[u], fy[u]);
+                  pair_force<T>(pax - bx(q + u), pay - by(q + u), sa + d.size[q + u], d, fx[u], fy[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                   Fx = fx[u] + Fx;
                   Fy = fy[u] + Fy;
                 }
               }
-              for (; b < bend; ++b) {
+              for (; q < b1; ++q) {
                 T fx, fy;
-                pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
-                              sa + d.size[b], d, fx, fy);
+                pair_force<T>(pax - bx(q), pay - by(q), sa + d.size[q], d, fx, fy);
                 Fx = fx + Fx;
                 Fy = fy + Fy;
+              }
+            };
+            if (d.ncol_prefix >= 0) {
+#ifdef MPE_ABL_NO_PAIRS
+              const int bend = b + 1 < d.ncol_prefix ? b + 1 : d.ncol_prefix;
+#else
+              const int bend = d.ncol_prefix;
+#endif
+              if constexpr (LGLOB) {
+                const int mid = bend < A ? bend : A;
+                run(b, mid, bx_lds, by_lds);
+                run(mid > b ? mid : b, bend, bx_glb, by_glb);
+              } else {
+                run(b, bend, bx_lds, by_lds);
               }
             } else {
               for (; b < E; ++b) {
                 if (!bit(d.collide, b)) continue;
                 T fx, fy;
-                pair_force<T>(pax - sPos[(2 * b) * TILE + lane], pay - sPos[(2 * b + 1) * TILE + lane],
-                              sa + d.size[b], d, fx, fy);
+                if (LGLOB && b >= A) pair_force<T>(pax - bx_glb(b), pay - by_glb(b), sa + d.size[b], d, fx, fy);
+                else pair_force<T>(pax - bx_lds(b), pay - by_lds(b), sa + d.size[b], d, fx, fy);
                 Fx = fx + Fx;
                 Fy = fy + Fy;
               }
@@ -305,10 +389,28 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           if (active) {
             st_state(p.vel + (int64_t)(2 * a) * ld + env, vx);
             st_state(p.vel + (int64_t)(2 * a + 1) * ld + env, vy);
+            if constexpr (LGLOB) {  // core.py:222 now, from registers; LDS keeps the old position until phase 2
+              st_state(p.pos + (int64_t)(2 * a) * ld + env, sPos[(2 * a) * TILE + lane] + vx * d.dt);
+              st_state(p.pos + (int64_t)(2 * a + 1) * ld + env, sPos[(2 * a + 1) * TILE + lane] + vy * d.dt);
+            }
           }
         }
-        sVel[(2 * a) * TILE + lane] = vx;
-        sVel[(2 * a + 1) * TILE + lane] = vy;
+        if constexpr (LGLOB) {
+          if (p.obs != nullptr && active) {  // the agent's own velocity: rows 0, 1 of its observation
+            st_stream(p.obs + (int64_t)d.obs_row0[a] * ld + env, vx);
+            st_stream(p.obs + (int64_t)(d.obs_row0[a] + 1) * ld + env, vy);
+          }
+          if (KIND == MPE_SIMPLE_TAG && !bit(d.adversary, a)) {  // slot = number of good agents below a
+            const uint32_t lo = a < 32 ? ~d.adversary[0] & ((1u << (a & 31)) - 1u) : ~d.adversary[0];
+            const uint32_t hi = a < 32 ? 0u : ~d.adversary[1] & ((1u << (a & 31)) - 1u);
+            const int g = __builtin_popcount(lo) + __builtin_popcount(hi);
+            sVel[(2 * g) * TILE + lane] = vx;
+            sVel[(2 * g + 1) * TILE + lane] = vy;
+          }
+        } else {
+          sVel[(2 * a) * TILE + lane] = vx;
+          sVel[(2 * a + 1) * TILE + lane] = vy;
+        }
       }
       __syncthreads();
       // ---- phase 2: positions (core.py:222), comm (core.py:226-227) -----------------------------
@@ -317,9 +419,13 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const int r = 2 * a + c;
-            const T np_ = sPos[r * TILE + lane] + sVel[r * TILE + lane] * d.dt;
-            sPos[r * TILE + lane] = np_;
-            if (active) st_state(p.pos + (int64_t)r * ld + env, np_);
+            if constexpr (LGLOB) {  // what this very thread stored in phase 1 (inactive lanes shadow env B - 1, store nothing)
+              sPos[r * TILE + lane] = ld_state(p.pos + (int64_t)r * ld + ge);
+            } else {
+              const T np_ = sPos[r * TILE + lane] + sVel[r * TILE + lane] * d.dt;
+              sPos[r * TILE + lane] = np_;
+              if (active) st_state(p.pos + (int64_t)r * ld + env, np_);
+            }
           }
         }
         if (p.comm != nullptr && active) {  // core.py:226-230
@@ -352,7 +458,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
       if (p.obs != nullptr && active && p.B < 0) {
 #else
       if (VEC_OBS && p.obs != nullptr) {
-        obs_rows_vec<T, TILE, THREADS, KIND == MPE_SIMPLE_TAG>(p, sPos, sVel, tile);
+        obs_rows_vec<T, TILE, THREADS, KIND == MPE_SIMPLE_TAG, LGLOB>(p, sPos, sVel, tile);
       } else if (p.obs != nullptr && active) {
 #endif
         // simple_world_comm: which agents stand in forest 0 / forest 1 (is_collision, :240-245,258-259)
@@ -629,9 +735,13 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
         if (kind == MPE_SIMPLE_TAG) {
           // hit(g,a) = is_collision(good g, adversary a) (simple_tag.py:69-73), each pair evaluated
           // once by the chunk that owns g; per-adversary counts meet in LDS (ds_add, rare).
-          int *sCnt = reinterpret_cast<int *>(sAux);        // [n_adv][TILE]
-          int *sTot = sCnt + d.n_adv * TILE;                // [NCH][TILE]
-          for (int ai = chunk; ai < d.n_adv; ai += NCH) sCnt[ai * TILE + lane] = 0;
+          // LGLOB: four adversaries per int (8 bits each; a count is at most n_good <= 64), so that the scratch fits
+          // the good agents' velocity rows it aliases
+          constexpr int PK = LGLOB ? 4 : 1;
+          int *sCnt = reinterpret_cast<int *>(sAux);        // [ceil(n_adv / PK)][TILE]
+          const int ncnt = (d.n_adv + PK - 1) / PK;
+          int *sTot = sCnt + ncnt * TILE;                   // [NCH][TILE]
+          for (int ai = chunk; ai < ncnt; ai += NCH) sCnt[ai * TILE + lane] = 0;
           __syncthreads();
           int part = 0;  // this chunk's share of sum_{g,a} hit
           for (int gi = chunk; gi < d.n_good; gi += NCH) {
@@ -644,7 +754,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
               if (touching<T>(pgx - sPos[(2 * a) * TILE + lane], pgy - sPos[(2 * a + 1) * TILE + lane],
                               sg + d.size[a])) {
                 ++n;
-                atomicAdd(&sCnt[ai * TILE + lane], 1);
+                atomicAdd(&sCnt[(ai / PK) * TILE + lane], 1 << (8 * (ai % PK)));
               }
             }
             part += n;
@@ -668,7 +778,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const KParams<T> p) {
           // benchmark_data (simple_tag.py:57-64): goods touching this adversary
           for (int ai = chunk; ai < d.n_adv; ai += NCH) {
             const int i = d.adv_list[ai];
-            const int n = sCnt[ai * TILE + lane];
+            const int n = LGLOB ? (sCnt[(ai / PK) * TILE + lane] >> (8 * (ai % PK))) & 0xFF : sCnt[ai * TILE + lane];
             const T r_i = bit(d.collide, i) ? T(10) * T(total) : T(0);
             if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
             if (want_info && active) st_stream(p.info + (int64_t)i * ld + env, T(n));
@@ -1017,6 +1127,20 @@ inline size_t tile_lds_bytes(const mpe_scenario_desc *h, int threads) {
   for (int a = 0; a < h->n_agents; ++a)
     if (h->forced_id[a] >= 0) lfb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
   return (size_t)(2 * E) * TILE * sizeof(T) + lfb + velb;
+}
+
+// LDS bytes of the LGLOB form (simple_tag, fused step): agents' positions + max(good agents' velocity rows, reward scratch).
+template <typename T>
+inline size_t tile_lds_bytes_lglob(const mpe_scenario_desc *h, int threads) {
+  constexpr int TILE = tile_envs<T>();
+  const int NCH = threads / TILE;
+  int n_good = 0;
+  for (int a = 0; a < h->n_agents; ++a) n_good += h->adversary[a] ? 0 : 1;
+  const int n_adv = h->n_agents - n_good;
+  size_t velb = (size_t)(2 * n_good) * TILE * sizeof(T);
+  const size_t aux = (size_t)((n_adv + 3) / 4 + NCH) * TILE * sizeof(int);
+  if (velb < aux) velb = aux;
+  return (size_t)(2 * h->n_agents) * TILE * sizeof(T) + velb;
 }
 
 }  // namespace mpe

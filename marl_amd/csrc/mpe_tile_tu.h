@@ -27,11 +27,16 @@ static int grant_lds(K kern, size_t lds, size_t *granted /*[kMaxDevices]*/) {
   return 0;
 }
 
-template <typename T, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER, int KIND>
+// Workgroup size of the LGLOB form (its register budget: mpe_tile_kernel.h, MPE_TILE_ATTR)
+#ifndef MPE_LGLOB_THREADS
+#define MPE_LGLOB_THREADS 512
+#endif
+
+template <typename T, int THREADS, bool DO_STEP, bool DO_OBS, bool HIER, int KIND, bool LGLOB = false>
 static int launch_tile_k(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   constexpr int TILE = tile_envs<T>();
-  const size_t lds = tile_lds_bytes<T>(h, THREADS);
-  auto kern = tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, HIER, KIND>;
+  const size_t lds = LGLOB ? tile_lds_bytes_lglob<T>(h, THREADS) : tile_lds_bytes<T>(h, THREADS);
+  auto kern = tile_kernel<T, TILE, THREADS, DO_STEP, DO_OBS, HIER, KIND, LGLOB>;
   if (lds > 64 * 1024) {
     if (lds > 160 * 1024) return MPE_ERR_UNSUPPORTED;
     static size_t granted[64] = {};
@@ -47,7 +52,17 @@ template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
 static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStream_t s) {
   if (tile_kind_is_ragged(h->kind)) return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, true, -1>(h, p, s);
   // the north-star scenarios get their own instantiation (mpe_tile_kernel.h: KIND)
-  if (h->kind == MPE_SIMPLE_TAG) return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_TAG>(h, p, s);
+  if (h->kind == MPE_SIMPLE_TAG) {
+#ifndef MPE_TILE_NO_LGLOB
+    // worlds whose full tile leaves room for fewer than four workgroups per CU keep the landmarks in global memory
+    // (mpe_tile_kernel.h: LGLOB): the fused step only, f32 (the f64 tile is 32 envs: half the bytes per row already)
+    if constexpr (DO_STEP && DO_OBS && sizeof(T) == 4) {
+      if (h->n_landmarks > 0 && tile_lds_bytes<T>(h, THREADS) > 40 * 1024)
+        return launch_tile_k<T, MPE_LGLOB_THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_TAG, true>(h, p, s);
+    }
+#endif
+    return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_TAG>(h, p, s);
+  }
   if (h->kind == MPE_SIMPLE_SPREAD) return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_SPREAD>(h, p, s);
   return launch_tile_k<T, THREADS, DO_STEP, DO_OBS, false, -1>(h, p, s);
 }
