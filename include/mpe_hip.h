@@ -412,6 +412,25 @@ int mpe_replay_gather_f64(int64_t capacity, int width, const int64_t *idx, int64
                           void *out, void *stream);
 
 /*
+ * COMPACT replay records: obs_tp1 of a transition is obs_t of the same env's next transition, so a ring that is
+ * appended to one step of n envs at a time can store it once.  The caller keeps
+ *     ring [capacity][od + ad + 2]   records (obs_t | act | rew | done), appended with mpe_replay_add* (4 segments)
+ *     ends [capacity][od]            obs_tp1 of the steps that have no successor in the ring -- the last step of an
+ *                                    episode (the loop's `terminal`, experiments/simple_train.py:283,293-294) or the
+ *                                    newest step when a sample is drawn --, appended with mpe_replay_add* (1 segment)
+ *                                    at the same position as the step's records
+ *     own  [capacity / n] uint8      per step slot: 1 = obs_tp1 is in `ends`, 0 = it is obs_t of row (i + n) % capacity
+ * with capacity % n == 0 and every append exactly n transitions.  mpe_replay_gather_compact returns the rows in the FULL
+ * layout of mpe_replay_gather, out [batch][2 od + ad + 2] = (obs_t | act | rew | obs_tp1 | done): the same bytes as a
+ * full ring fed the same transitions (tests/test_gpu_replay.py), for 40 % fewer bytes per appended step.  No
+ * counterpart in the reference (its buffer is a Python list of tuples, replay_buffer.py:25-32).
+ */
+int mpe_replay_gather_compact_f32(int64_t capacity, int od, int ad, int64_t n, const int64_t *idx, int64_t batch,
+                                  const void *ring, const void *ends, const uint8_t *own, void *out, void *stream);
+int mpe_replay_gather_compact_f64(int64_t capacity, int od, int ad, int64_t n, const int64_t *idx, int64_t batch,
+                                  const void *ring, const void *ends, const uint8_t *own, void *out, void *stream);
+
+/*
  * Actor forward of the learner for every env in one launch (maddpg/maddpg/trainer/maddpg.py:39-45,151-152;
  * model experiments/train_and_eval.py:94-101; sample common/distributions.py:199-201,247-251):
  *     act = softmax_per_sub_space(W3 relu(W2 relu(W1 obs + b1) + b2) + b3 - log(-log(u)))

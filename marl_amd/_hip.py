@@ -153,6 +153,8 @@ def _load():
         f.restype, f.argtypes = ci, [ci, C.POINTER(ReplayJob), i64, vp]
         f = getattr(L, 'mpe_replay_gather_' + suf)    # capacity, width, idx, batch, ring, out, stream
         f.restype, f.argtypes = ci, [i64, ci, vp, i64, vp, vp, vp]
+        f = getattr(L, 'mpe_replay_gather_compact_' + suf)  # capacity, od, ad, n, idx, batch, ring, ends, own, out, stream
+        f.restype, f.argtypes = ci, [i64, ci, ci, i64, vp, i64, vp, vp, vp, vp, vp]
     # B, ld_obs, ld_act, in_dim, s0, s1, obs, weights, u, seed, call_counter, env_id0, act, stream
     L.mpe_actor_forward_f32.restype = ci
     L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]

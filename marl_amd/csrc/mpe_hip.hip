@@ -1202,6 +1202,70 @@ static int replay_add_multi_impl(int n_jobs, const mpe_replay_job *jobs, const i
   return MPE_OK;
 }
 
+// Gather from a COMPACT ring (include/mpe_hip.h, mpe_replay_gather_compact): records (obs_t | act | rew | done) of
+// width cw = od + ad + 2; obs_tp1 of row i is obs_t of row (i + n) % capacity (the same env one step later) unless the
+// row's step slot i / n is flagged: then its own copy ends[i][od].  Output rows keep the full layout
+// (obs_t | act | rew | obs_tp1 | done), so callers see what mpe_replay_gather gives them.
+template <typename T>
+__global__ __launch_bounds__(256) void replay_gather_compact_kernel(int64_t capacity, int od, int ad, int64_t n,
+                                                                     const int64_t *idx, int64_t total, const T *ring,
+                                                                     const T *ends, const uint8_t *own, T *out) {
+  const int width = 2 * od + ad + 2, cw = od + ad + 2;
+  const int64_t blk = (int64_t)blockIdx.x * 1024;
+  const int64_t b0 = blk / width;
+  const uint32_t off0 = (uint32_t)(blk - b0 * width);
+  const int64_t g0 = blk + threadIdx.x;
+  T v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t g = g0 + 256 * u;
+    v[u] = T(0);
+    if (g < total) {
+      const uint32_t t = off0 + threadIdx.x + 256u * u;
+      const uint32_t db = t / (uint32_t)width;
+      const int j = (int)(t - db * (uint32_t)width);
+      int64_t i = idx[b0 + db];
+      if ((uint64_t)i >= (uint64_t)capacity) {  // out of range: wrap instead of faulting
+        i %= capacity;
+        i = i < 0 ? i + capacity : i;
+      }
+      if (j < od + ad + 1) {  // obs_t | act | rew
+        v[u] = ring[i * cw + j];
+      } else if (j == width - 1) {  // done
+        v[u] = ring[i * cw + cw - 1];
+      } else {  // obs_tp1, column c
+        const int c = j - (od + ad + 1);
+        if (own[i / n]) {
+          v[u] = ends[i * od + c];
+        } else {
+          int64_t nx = i + n;
+          nx = nx >= capacity ? nx - capacity : nx;
+          v[u] = ring[nx * cw + c];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t g = g0 + 256 * u;
+    if (g < total) out[g] = v[u];
+  }
+}
+
+template <typename T>
+static int replay_gather_compact_impl(int64_t capacity, int od, int ad, int64_t n, const int64_t *idx, int64_t batch,
+                                      const void *ring, const void *ends, const uint8_t *own, void *out, void *stream) {
+  if (!idx || !ring || !ends || !own || !out) return MPE_ERR_NULL;
+  if (capacity < 1 || od < 1 || ad < 1 || n < 1 || capacity % n != 0 || batch < 0) return MPE_ERR_ARG;
+  if (misaligned<T>(ring) || misaligned<T>(ends) || misaligned<T>(out) || misaligned<int64_t>(idx)) return MPE_ERR_ALIGN;
+  if (batch == 0) return MPE_OK;
+  const int64_t total = batch * (2 * od + ad + 2);
+  const dim3 grid((unsigned)((total + 1023) / 1024)), block(256);
+  hipLaunchKernelGGL(replay_gather_compact_kernel<T>, grid, block, 0, (hipStream_t)stream, capacity, od, ad, n, idx,
+                     total, (const T *)ring, (const T *)ends, own, (T *)out);
+  return (int)hipGetLastError();
+}
+
 template <typename T>
 static int replay_gather_impl(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
                               void *out, void *stream) {
@@ -1431,6 +1495,11 @@ extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, 
   extern "C" int mpe_replay_gather_##SUF(int64_t capacity, int width, const int64_t *idx, int64_t batch,       \
                                          const void *ring, void *out, void *stream) {                          \
     return replay_gather_impl<T>(capacity, width, idx, batch, ring, out, stream);                              \
+  }                                                                                                            \
+  extern "C" int mpe_replay_gather_compact_##SUF(int64_t capacity, int od, int ad, int64_t n, const int64_t *idx,       \
+                                                 int64_t batch, const void *ring, const void *ends,                  \
+                                                 const uint8_t *own, void *out, void *stream) {                      \
+    return replay_gather_compact_impl<T>(capacity, od, ad, n, idx, batch, ring, ends, own, out, stream);            \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
                                  uint32_t episode, uint64_t env_id0, const uint8_t *mask,                      \

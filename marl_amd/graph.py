@@ -124,7 +124,8 @@ class CapturedTrainSteps(object):
         self._base_idx = [b._next_idx for b in self.buffers]
         self._slot0 = w._obs_slot
         self._noise_base = (w.noise_step - w._noise_dev_val) & 0xFFFFFFFF
-        host = ([tr._act_calls for tr in self.trainers], [(b._next_idx, b._len, getattr(b, '_keep', None)) for b in self.buffers],
+        host = ([tr._act_calls for tr in self.trainers],
+                [(b._next_idx, b._len, getattr(b, '_keep', None), b._pending) for b in self.buffers],
                 (w._tick, w._obs_tick, w._gather_tick, w.act, w.noise_step))
         self.graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(w.device)
@@ -132,10 +133,12 @@ class CapturedTrainSteps(object):
             with _hip.on_device(w.device):
                 with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                     obs_n = [w.obs_views[i] for i in env._pidx]
-                    for _ in range(self.K):
+                    for k in range(self.K):
                         action_n = act_all(self.trainers, obs_n, out=env.action_views, kernel=kernel, counter_dev=self.ctr)
                         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
-                        add_all(self.buffers, obs_n, action_n, rew_n, new_obs_n, done_n, cursors=True)
+                        # compact rings: the last recorded step keeps its own obs_tp1 (an episode reset follows a replay)
+                        add_all(self.buffers, obs_n, action_n, rew_n, new_obs_n, done_n, cursors=True,
+                                terminal=(k == self.K - 1))
                         obs_n = new_obs_n
                     self.last = (new_obs_n, rew_n, done_n, info_n)
             self._slot_after = w._obs_slot
@@ -145,8 +148,8 @@ class CapturedTrainSteps(object):
             # a capture executes nothing, but the host-side bookkeeping moved: put it back (also after a failed capture)
             for tr, c in zip(self.trainers, host[0]):
                 tr._act_calls = c
-            for b, (i, l, k) in zip(self.buffers, host[1]):
-                b._next_idx, b._len, b._keep = i, l, k
+            for b, (i, l, k, pend) in zip(self.buffers, host[1]):
+                b._next_idx, b._len, b._keep, b._pending = i, l, k, pend
             w._tick, w._obs_tick, w._gather_tick, w.act, w.noise_step = host[2]
             self._set_slot(self._slot0)
 
@@ -178,6 +181,11 @@ class CapturedTrainSteps(object):
         for tr in self.trainers:
             tr._act_calls += self.K
         for b in self.buffers:
+            if b.compact:          # the recorded appends do not touch the step-slot flags: K - 1 chained steps, then one
+                s0, S = b._next_idx // b._n, b._maxsize // b._n     # with its own copy of obs_tp1
+                for j in range(self.K):
+                    b._set_own((s0 + j) % S, 1 if j == self.K - 1 else 0)
+                b._pending = None
             b._next_idx = (b._next_idx + self.K * self._n) % b._maxsize
             b._len = min(b._len + self.K * self._n, b._maxsize)
         self._set_slot(self._slot_after)
@@ -243,6 +251,8 @@ class CapturedUpdates(object):
 
     def _draw(self):
         for tr, idx in zip(self.trainers, self.index):
+            if tr.replay_buffer.compact:               # outside the graph: the recorded gathers then find every step
+                tr.replay_buffer._flush_pending()      # either chained to its successor or with its own obs_tp1
             idx.copy_(tr.replay_buffer.make_index(idx.numel()))
             tr.replay_sample_index = idx
 

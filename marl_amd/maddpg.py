@@ -172,7 +172,7 @@ class MADDPGAgentTrainer(object):
     appends one step of all B envs to this agent's replay ring."""
 
     def __init__(self, name, obs_shape_n, act_space_n, agent_index, args, local_q_func=False, model=mlp_model,
-                 device='cuda', dtype=torch.float32, replay_size=1e6, seed=0, env_id0=0):
+                 device='cuda', dtype=torch.float32, replay_size=1e6, seed=0, env_id0=0, replay_compact=False):
         """``seed``: the run's seed (keys the exploration noise of the fused actor kernel together with the agent
         index); ``env_id0``: global id of this process's env 0 (``world.env_id0`` of an env-sharded multi-GPU run), so
         that the noise of env ``i`` does not depend on how the batch is sharded -- like the reset RNG."""
@@ -195,7 +195,7 @@ class MADDPGAgentTrainer(object):
         self.p_opt = torch.optim.Adam(self.p.parameters(), lr=args.lr, eps=1e-8)
         self.q_opt = torch.optim.Adam(self.q.parameters(), lr=args.lr, eps=1e-8)
         self.grad_norm_clipping = 0.5                                     # maddpg.py:130,142
-        self.replay_buffer = ReplayBuffer(replay_size, device=self.device, dtype=dtype)   # maddpg.py:147
+        self.replay_buffer = ReplayBuffer(replay_size, device=self.device, dtype=dtype, compact=replay_compact)   # maddpg.py:147
         self.max_replay_buffer_len = args.batch_size * args.max_episode_len
         self.replay_sample_index = None
         self._packed = None            # packed actor weights for the fused kernel; dropped by every update
@@ -228,7 +228,7 @@ class MADDPGAgentTrainer(object):
 
     def experience(self, obs, act, rew, new_obs, done, terminal):
         """maddpg.py:154-156."""
-        self.replay_buffer.add(obs, act, rew, new_obs, done)
+        self.replay_buffer.add(obs, act, rew, new_obs, done, terminal if self.replay_buffer.compact else None)
 
     def preupdate(self):                # maddpg.py:158-159
         self.replay_sample_index = None

@@ -5,7 +5,14 @@ Same methods as the reference class.  ``add`` takes one step of all B envs at on
 ``env.step`` returns them (transposed views of the kernels' SoA rows) or any other strides, ``[B]`` rewards
 and dones -- and equals B reference ``add()`` calls in env order.  Records are stored transition-major
 (``[capacity, width]``, width = obs + act + 1 + obs + 1), so ``sample_index`` is one row gather that returns
-``[batch, d]`` tensors ready for the networks.  libmpe_hip.so: mpe_replay_add_*, mpe_replay_gather_*."""
+``[batch, d]`` tensors ready for the networks.  libmpe_hip.so: mpe_replay_add_*, mpe_replay_gather_*.
+
+``ReplayBuffer(size, compact=True)`` stores ``obs_tp1`` once: it is the next step's ``obs_t`` of the same env, so the
+ring keeps (obs_t | act | rew | done) and looks the successor row up when a batch is gathered (40 % fewer bytes per
+appended step for simple_tag's 39-column records).  Steps without a successor -- the last one of an episode, which the
+loop announces with ``terminal`` exactly as the reference's ``experience(..., terminal)`` receives it
+(maddpg.py:154, experiments/simple_train.py:283-287), and the newest one whenever a sample is drawn -- keep their own
+copy.  Needs ``size % num_envs == 0``; samples are bit-identical to the full ring's (tests/test_gpu_replay.py)."""
 import ctypes as C
 
 import torch
@@ -14,8 +21,14 @@ from . import _hip
 
 
 class ReplayBuffer(object):
-    def __init__(self, size, device=None, dtype=torch.float32):
+    def __init__(self, size, device=None, dtype=torch.float32, compact=False):
         """replay_buffer.py:5-16.  ``size``: max number of transitions; old ones are overwritten."""
+        self.compact = bool(compact)
+        self._ends = None          # compact: [capacity, od] own obs_tp1 copies (rows of steps flagged in _own)
+        self._own = None           # compact: uint8 [capacity / n] device flags, _own_host their host shadow
+        self._own_host = None
+        self._n = None             # compact: transitions per append (fixed by the first one)
+        self._pending = None       # compact: (first ring row, obs_tp1 tensor) of the newest step, added with terminal=False
         self._maxsize = int(size)
         self._next_idx = 0
         self._len = 0
@@ -34,6 +47,7 @@ class ReplayBuffer(object):
     def clear(self):               # :21-23
         self._len = 0
         self._next_idx = 0
+        self._pending = None
 
     def device_cursor(self):
         """int64 device word that ``add_all(..., cursors=True)`` adds to the append position (mpe_replay_add_multi_cur_*):
@@ -46,7 +60,7 @@ class ReplayBuffer(object):
         """Whether ``add_all(..., cursors=True)`` of n transitions can append to this (already allocated) buffer: the
         one-launch kernel of mpe_replay_add_multi_cur_* holds a 256-transition tile of the record plus its column tables
         in 64 KiB of LDS (records of <= 61 f32 / 30 f64 columns) and needs a full tile."""
-        width = self._ring.shape[1]
+        width = max(self._ring.shape[1], self._dims[0] if self.compact else 0)
         esize = self._ring.element_size()
         return width * 257 * esize + 160 * 16 <= 64 * 1024 and min(n, self._maxsize) >= 256
 
@@ -62,31 +76,85 @@ class ReplayBuffer(object):
             raise ValueError('expected %d transitions, got a tensor of shape %s' % (n, tuple(t.shape)))
         return t, _hip.ReplaySeg(t.data_ptr(), t.shape[1], t.stride(1), t.stride(0))
 
-    def _prepare(self, obs_t, action, reward, obs_tp1, done):
-        """Segment table of one append (allocates the ring on first use): (n, width, segment array, keep-alive)."""
+    def _prepare(self, obs_t, action, reward, obs_tp1, done, terminal=None):
+        """The appends of one step (allocates the ring on first use): (n, jobs, keep-alive); a job is
+        (width, segment array, number of segments, destination ring).  Full records: one job of five segments.  Compact:
+        (obs_t | act | rew | done) into the ring, plus obs_tp1 into ``_ends`` unless ``terminal`` is False."""
         n = reward.shape[0]
         keep, segs = zip(*[self._seg(t, n) for t in (obs_t, action, reward, obs_tp1, done)])
         width = sum(s.rows for s in segs)
+        od, ad = segs[0].rows, segs[1].rows
         if self._ring is None:
-            self._dims = (segs[0].rows, segs[1].rows)
-            self._ring = torch.zeros(self._maxsize, width, dtype=self.dtype, device=self.device)
-        elif (segs[0].rows, segs[1].rows) != self._dims or segs[3].rows != self._dims[0]:
-            raise ValueError('transition shape changed: %s' % ((segs[0].rows, segs[1].rows),))
-        return n, width, (_hip.ReplaySeg * 5)(*segs), keep
+            self._dims = (od, ad)
+            if self.compact:
+                if n < 1 or self._maxsize % n != 0 or self._maxsize // n < 2:
+                    raise ValueError('a compact replay buffer needs size %% num_envs == 0 and room for two steps '
+                                     '(size %d, %d transitions per step)' % (self._maxsize, n))
+                self._n = n
+                self._ring = torch.zeros(self._maxsize, width - od, dtype=self.dtype, device=self.device)
+                self._ends = torch.zeros(self._maxsize, od, dtype=self.dtype, device=self.device)
+                self._own = torch.ones(self._maxsize // n, dtype=torch.uint8, device=self.device)
+                self._own_host = [1] * (self._maxsize // n)
+            else:
+                self._ring = torch.zeros(self._maxsize, width, dtype=self.dtype, device=self.device)
+        elif (od, ad) != self._dims or segs[3].rows != self._dims[0]:
+            raise ValueError('transition shape changed: %s' % ((od, ad),))
+        if not self.compact:
+            return n, [(width, (_hip.ReplaySeg * 5)(*segs), 5, self._ring)], keep
+        if n != self._n:
+            raise ValueError('a compact replay buffer takes %d transitions per append, got %d' % (self._n, n))
+        if self._pending is not None:
+            # the previous step was added with terminal=False: this step's obs_t IS its obs_tp1 (nothing was copied)
+            t = keep[0]
+            prev = self._pending[1]
+            if t.data_ptr() != prev.data_ptr() or t.stride() != prev.stride() or t.shape != prev.shape:
+                raise ValueError('compact replay buffer: the previous add() was not flagged terminal, so this obs_t must '
+                                 'be the tensor that was its obs_tp1 (pass terminal=True to the add() before a reset)')
+        jobs = [(width - od, (_hip.ReplaySeg * 4)(segs[0], segs[1], segs[2], segs[4]), 4, self._ring)]
+        if terminal is None or terminal:
+            jobs.append((od, (_hip.ReplaySeg * 1)(segs[3]), 1, self._ends))
+        return n, jobs, keep
 
-    def _advance(self, n, keep):
+    def _set_own(self, slot, value):
+        if self._own_host[slot] != value:
+            self._own_host[slot] = value
+            self._own[slot] = value
+
+    def _advance(self, n, keep, terminal=None, flags=True):
         self._keep = keep          # sources stay alive until the stream has consumed them
+        if self.compact:
+            own = terminal is None or bool(terminal)
+            if flags:              # (appends recorded in a HIP graph: marl_amd.graph sets the flags after each replay)
+                self._set_own(self._next_idx // self._n, 1 if own else 0)
+            self._pending = None if own else (self._next_idx, keep[3])
         self._next_idx = (self._next_idx + n) % self._maxsize
         self._len = min(self._len + n, self._maxsize)
 
-    def add(self, obs_t, action, reward, obs_tp1, done):
-        """replay_buffer.py:25-32 for one step of B envs (= B add() calls in env order)."""
-        n, width, arr, keep = self._prepare(obs_t, action, reward, obs_tp1, done)
+    def _flush_pending(self):
+        """Compact: a sample is about to be drawn while the newest step has no successor yet: give it its own copy of
+        obs_tp1 (one [n, od] copy per draw, i.e. per 100 steps in the reference's loop)."""
+        if self._pending is None:
+            return
+        row0, t = self._pending
+        t, seg = self._seg(t, self._n)
         fn = getattr(_hip.lib, 'mpe_replay_add_' + _hip.suffix(self.dtype))
         with _hip.on_device(self.device):
-            _hip.check(fn(self._maxsize, self._next_idx, n, width, 5, arr, self._ring.data_ptr(),
+            _hip.check(fn(self._maxsize, row0, self._n, self._dims[0], 1, (_hip.ReplaySeg * 1)(seg), self._ends.data_ptr(),
                           _hip.stream_of(self.device)), 'mpe_replay_add')
-        self._advance(n, keep)
+        self._set_own(row0 // self._n, 1)
+        self._pending = None
+
+    def add(self, obs_t, action, reward, obs_tp1, done, terminal=None):
+        """replay_buffer.py:25-32 for one step of B envs (= B add() calls in env order).  ``terminal`` (compact buffers
+        only; what the reference's loop hands to ``experience``): False = the next add() continues these episodes, so
+        its obs_t is this obs_tp1 and nothing is copied now; True / None = this step keeps its own copy."""
+        n, jobs, keep = self._prepare(obs_t, action, reward, obs_tp1, done, terminal)
+        fn = getattr(_hip.lib, 'mpe_replay_add_' + _hip.suffix(self.dtype))
+        with _hip.on_device(self.device):
+            for width, arr, nseg, ring in jobs:
+                _hip.check(fn(self._maxsize, self._next_idx, n, width, nseg, arr, ring.data_ptr(),
+                              _hip.stream_of(self.device)), 'mpe_replay_add')
+        self._advance(n, keep, terminal)
 
     def _encode_sample(self, idxes):
         """replay_buffer.py:34-44: (obs [b, od], act [b, ad], rew [b], obs_next [b, od], done [b])."""
@@ -103,11 +171,18 @@ class ReplayBuffer(object):
             if int(lo) < 0 or int(hi) >= self._len:
                 raise IndexError('replay index out of range [0, %d): min %d, max %d' % (self._len, int(lo), int(hi)))
         od, ad = self._dims
-        out = torch.empty(b, self._ring.shape[1], dtype=self.dtype, device=self.device)
-        fn = getattr(_hip.lib, 'mpe_replay_gather_' + _hip.suffix(self.dtype))
+        out = torch.empty(b, 2 * od + ad + 2, dtype=self.dtype, device=self.device)
         with _hip.on_device(self.device):
-            _hip.check(fn(self._maxsize, out.shape[1], idxes.data_ptr(), b, self._ring.data_ptr(), out.data_ptr(),
-                          _hip.stream_of(self.device)), 'mpe_replay_gather')
+            if self.compact:
+                self._flush_pending()
+                fn = getattr(_hip.lib, 'mpe_replay_gather_compact_' + _hip.suffix(self.dtype))
+                _hip.check(fn(self._maxsize, od, ad, self._n, idxes.data_ptr(), b, self._ring.data_ptr(),
+                              self._ends.data_ptr(), self._own.data_ptr(), out.data_ptr(), _hip.stream_of(self.device)),
+                           'mpe_replay_gather_compact')
+            else:
+                fn = getattr(_hip.lib, 'mpe_replay_gather_' + _hip.suffix(self.dtype))
+                _hip.check(fn(self._maxsize, out.shape[1], idxes.data_ptr(), b, self._ring.data_ptr(), out.data_ptr(),
+                              _hip.stream_of(self.device)), 'mpe_replay_gather')
         return (out[:, :od], out[:, od:od + ad], out[:, od + ad], out[:, od + ad + 1:2 * od + ad + 1],
                 out[:, 2 * od + ad + 1])
 
@@ -136,10 +211,11 @@ class ReplayBuffer(object):
         return self.sample(-1)
 
 
-def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n, cursors=False):
+def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n, cursors=False, terminal=None):
     """``buffers[i].add(obs_n[i], action_n[i], reward_n[i], obs_tp1_n[i], done_n[i])`` for every agent (the loop of
     experiments/simple_train.py:284-287) in ONE launch (libmpe_hip.so: mpe_replay_add_multi_*).
-    ``cursors``: append at ``_next_idx + *device_cursor()`` (mpe_replay_add_multi_cur_*; for HIP-graph capture)."""
+    ``cursors``: append at ``_next_idx + *device_cursor()`` (mpe_replay_add_multi_cur_*; for HIP-graph capture).
+    ``terminal``: see ``ReplayBuffer.add`` (compact buffers)."""
     b0 = buffers[0]
     if any(b.device != b0.device or b.dtype != b0.dtype for b in buffers):
         raise ValueError('add_all needs buffers on one device with one dtype')
@@ -147,19 +223,21 @@ def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n, cursors=False
     if all(torch.is_tensor(d) and d is done_n[0] for d in done_n) and done_n[0].dtype != b0.dtype:
         # env.step hands every agent the same bool tensor (environment.py:108): convert it once, not per buffer
         done_n = [done_n[0].to(b0.dtype)] * len(done_n)
-    prep = [b._prepare(*args) for b, args in zip(buffers, zip(obs_n, action_n, reward_n, obs_tp1_n, done_n))]
+    prep = [b._prepare(*args, terminal) for b, args in zip(buffers, zip(obs_n, action_n, reward_n, obs_tp1_n, done_n))]
     n = prep[0][0]
     if any(p[0] != n for p in prep):
         raise ValueError('every agent must add the same number of transitions')
-    jobs = (_hip.ReplayJob * len(buffers))(*[_hip.ReplayJob(b._maxsize, b._next_idx, p[1], 5, p[2], b._ring.data_ptr())
-                                             for b, p in zip(buffers, prep)])
+    owners = [b for b, p in zip(buffers, prep) for _ in p[1]]
+    flat = [j for p in prep for j in p[1]]
+    jobs = (_hip.ReplayJob * len(flat))(*[_hip.ReplayJob(b._maxsize, b._next_idx, width, nseg, arr, ring.data_ptr())
+                                          for b, (width, arr, nseg, ring) in zip(owners, flat)])
     with _hip.on_device(b0.device):
         if cursors:
-            cur = (C.c_void_p * len(buffers))(*[b.device_cursor().data_ptr() for b in buffers])
+            cur = (C.c_void_p * len(flat))(*[b.device_cursor().data_ptr() for b in owners])
             fn = getattr(_hip.lib, 'mpe_replay_add_multi_cur_' + _hip.suffix(b0.dtype))
-            _hip.check(fn(len(buffers), jobs, cur, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi_cur')
+            _hip.check(fn(len(flat), jobs, cur, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi_cur')
         else:
             fn = getattr(_hip.lib, 'mpe_replay_add_multi_' + _hip.suffix(b0.dtype))
-            _hip.check(fn(len(buffers), jobs, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi')
+            _hip.check(fn(len(flat), jobs, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi')
     for b, p in zip(buffers, prep):
-        b._advance(n, p[3])
+        b._advance(n, p[2], terminal, flags=not cursors)

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B, seed=0):
+def _setup(B, seed=0, compact=False):
     from marl_amd import make_env
     from marl_amd.maddpg import MADDPGAgentTrainer
     env = make_env('simple_tag', num_envs=B, dtype=torch.float32, seed=seed)
@@ -17,22 +17,23 @@ def _setup(B, seed=0):
     obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
     torch.manual_seed(123)                                   # identical initial networks in both copies
     trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=B * 40,
-                                   seed=seed, env_id0=env.world.env_id0) for i in range(env.n)]
+                                   seed=seed, env_id0=env.world.env_id0, replay_compact=compact)
+                for i in range(env.n)]
     return env, trainers
 
 
-def _iteration(env, trainers, obs_n):
+def _iteration(env, trainers, obs_n, terminal=None):
     from marl_amd.maddpg import act_all
     from marl_amd.replay_buffer import add_all
     action_n = act_all(trainers, obs_n, out=env.action_views)
     new_obs_n, rew_n, done_n, info_n = env.step(action_n)
-    add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n)
+    add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n, terminal=terminal)
     return new_obs_n
 
 
-def _run(B, K, graph):
+def _run(B, K, graph, compact=False):
     from marl_amd.graph import CapturedTrainSteps
-    env, trainers = _setup(B)
+    env, trainers = _setup(B, compact=compact)
     obs_n = env.reset()
     obs_n = _iteration(env, trainers, obs_n)                 # rings and packed weights exist after this
     obs_n = env.reset()
@@ -41,8 +42,8 @@ def _run(B, K, graph):
     def block(obs_n):
         if cap is not None:
             return cap.replay()[0]
-        for _ in range(K):
-            obs_n = _iteration(env, trainers, obs_n)
+        for k in range(K):
+            obs_n = _iteration(env, trainers, obs_n, terminal=k == K - 1)
         return obs_n
 
     obs_n = block(obs_n)
@@ -58,7 +59,8 @@ def _run(B, K, graph):
     torch.cuda.synchronize()
     rings = [tr.replay_buffer._ring.clone() for tr in trainers]
     book = [(tr._act_calls, tr.replay_buffer._next_idx, len(tr.replay_buffer)) for tr in trainers]
-    return rings, book, env.world.pos.clone(), env.world.vel.clone(), [o.clone() for o in obs_n]
+    stored = [[x.clone() for x in tr.replay_buffer.collect()] for tr in trainers]     # (obs, act, rew, obs_next, done)
+    return rings, book, env.world.pos.clone(), env.world.vel.clone(), [o.clone() for o in obs_n], stored
 
 
 @pytest.mark.parametrize('K', [4, 5])
@@ -72,6 +74,23 @@ def test_captured_train_steps_equal_the_eager_loop(K):
     assert torch.equal(eager[2], captured[2]) and torch.equal(eager[3], captured[3])
     for a, b in zip(eager[4], captured[4]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('K', [4, 5])
+def test_compact_rings_in_the_eager_and_the_captured_loop_hold_the_full_rings_transitions(K):
+    """ReplayBuffer(compact=True) -- obs_tp1 stored once, `terminal` announced by the loop like the reference's
+    experience(..., terminal) -- through add_all and through CapturedTrainSteps (whose last recorded step keeps its own
+    copy): every stored transition as the trainers will sample it equals the full ring's, bit for bit."""
+    B = 512
+    full, eager, captured = _run(B, K, False), _run(B, K, False, compact=True), _run(B, K, True, compact=True)
+    assert full[1] == eager[1] == captured[1]
+    assert eager[0][0].shape[1] == full[0][0].shape[1] - 16      # the adversaries' rings lost their 16 obs_tp1 columns
+    for f, e, c in zip(full[5], eager[5], captured[5]):
+        for x, y, z in zip(f, e, c):
+            assert torch.equal(x, y) and torch.equal(x, z)
+    for a, b in zip(eager[0], captured[0]):                       # and the compact rings themselves agree
+        assert torch.equal(a, b)
+    assert torch.equal(full[2], captured[2]) and torch.equal(full[3], captured[3])
 
 
 def test_ring_wrap_inside_a_replay():

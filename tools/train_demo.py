@@ -1,9 +1,10 @@
 """The reference's training loop shape (experiments/simple_train.py:257-300) entirely on one GPU: batched env
 step -> per-agent replay rings -> MADDPG updates every 100 steps.  Prints agent-steps/s with the learner in the
 loop (run on the GPU box from the repo root):
-    python tools/train_demo.py [scenario] [num_envs] [steps] [eager]
+    python tools/train_demo.py [scenario] [num_envs] [steps] [eager|graph] [compact|full]
 One episode (25 iterations) is one HIP-graph replay (marl_amd.graph.CapturedTrainSteps) and the learners' updates
-another (CapturedUpdates) unless `eager` is given."""
+another (CapturedUpdates) unless `eager` is given.  `compact`: replay rings that store obs_tp1 once
+(marl_amd.replay_buffer.ReplayBuffer(compact=True))."""
 import os
 import sys
 import time
@@ -25,16 +26,18 @@ def main():
     args = types.SimpleNamespace(lr=1e-2, gamma=0.95, batch_size=1024, num_units=64, max_episode_len=25)
     env = make_env(scenario, num_envs=B, dtype=torch.float32, seed=0)
     obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
+    compact = len(sys.argv) > 5 and sys.argv[5] == 'compact'
     trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=1 << 22,
-                                   seed=0, env_id0=env.world.env_id0) for i in range(env.n)]
+                                   seed=0, env_id0=env.world.env_id0, replay_compact=compact) for i in range(env.n)]
     eager = len(sys.argv) > 4 and sys.argv[4] == 'eager'
     obs_n = env.reset()
     t0 = None
 
-    def iteration(obs_n):
+    def iteration(obs_n, terminal=True):
         action_n = act_all(trainers, obs_n, out=env.action_views)   # every agent's actor: one launch, no copies
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
-        add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n)   # one launch
+        add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n,
+                terminal=terminal)                                  # every agent's append: one launch
         return new_obs_n
 
     # one episode (25 iterations of act -> step -> store) is one HIP-graph replay; resets and updates stay outside
@@ -50,8 +53,8 @@ def main():
         if episode is not None:
             episode.replay()
         else:
-            for _ in range(EP):
-                obs_n = iteration(obs_n)
+            for k in range(EP):
+                obs_n = iteration(obs_n, terminal=k == EP - 1)      # experiments/simple_train.py:283: episode_step >= max_episode_len
         obs_n = env.reset()
         for tr in trainers:
             tr.preupdate()
@@ -68,8 +71,9 @@ def main():
             print('step %5d  q_loss %.4f  p_loss %.4f  mean reward %.3f' % (t, float(out[0]), float(out[1]), float(out[3])))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print('%s: %d envs x %d steps with %d learners in the loop (%s): %.3f ms/step, %.3e agent-steps/s'
-          % (scenario, B, steps, env.n, 'eager' if eager else 'one graph replay per episode', 1e3 * dt / steps,
+    print('%s: %d envs x %d steps with %d learners in the loop (%s, %s replay records): %.3f ms/step, %.3e agent-steps/s'
+          % (scenario, B, steps, env.n, 'eager' if eager else 'one graph replay per episode',
+             'compact' if compact else 'full', 1e3 * dt / steps,
              B * env.n * steps / dt))
 
 
