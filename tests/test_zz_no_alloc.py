@@ -83,3 +83,40 @@ def test_spread_and_size_limit():
     assert b'scratch' in lib.mpe_strerror(-7)
     assert lib.mpe_env_step_stats_static(sim.desc, 8, 8, bufs, 2, out.data_ptr(), sim.stream) == -6    # dtype_bytes
     assert lib.mpe_env_step_stats_static(sim.desc, 8, 8, bufs, 4, None, sim.stream) == -1
+
+
+def test_entry_point_under_hip_graph_capture_and_with_garbage_in_the_ignored_stats_member():
+    """What the header advertises: after one eager call on the device (which resolves the scratch array's address) the
+    entry point records under HIP graph capture -- it allocates nothing -- and a replay gives the eager call's bits.
+    buf->stats is documented as ignored: a misaligned / dangling value there must not be looked at."""
+    spec = O.simple_tag_spec()
+    B = 30_011
+    pos, vel, act = _state(spec, B, 5)
+    sims = [HipSim(spec, B, torch.float32, ld=B + 5) for _ in range(2)]
+    outs = []
+    side = torch.cuda.Stream()
+    for sim, captured in zip(sims, (False, True)):
+        sim.set_state(pos, vel)
+        act_d = torch.zeros(spec.n_agents, 5, sim.ld, dtype=torch.float32, device='cuda')
+        act_d[:, :, :B] = dev(act, torch.float32)
+        width = lib.mpe_stats_width(sim.desc)
+        out = torch.full((width,), float('nan'), dtype=torch.float64, device='cuda')
+        bufs = _hip.Buffers(pos=sim.pos, vel=sim.vel, goal=sim.goal, act=act_d, obs=sim.obs, rew=sim.rew, info=sim.info)
+        bufs.stats = 0xDEAD0003                                            # ignored: neither aligned nor mapped
+        if not captured:
+            rc = lib.mpe_env_step_stats_static(sim.desc, B, sim.ld, bufs, 4, out.data_ptr(), sim.stream)
+            assert rc == 0, lib.mpe_strerror(rc)
+        else:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                rc = lib.mpe_env_step_stats_static(sim.desc, B, sim.ld, bufs, 4, out.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.mpe_strerror(rc)
+            assert torch.isnan(out).all()                                   # a capture executes nothing
+            g.replay()
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and outs[0][-1] == B
+    for x, y in zip(sims[0].host(), sims[1].host()):
+        assert np.array_equal(x, y, equal_nan=True)
