@@ -23,7 +23,7 @@
  *     of the failed launch.  Never throws, never aborts.
  *   - Struct-of-arrays device layout, env index fastest ("row" = one scalar for all envs):
  *         pos  [E][2][ld]    E = n_agents + n_landmarks, agents first (core.py:109-111)
- *         vel  [A][2][ld]    landmarks never move in the supported scenarios
+ *         vel  [A][2][ld]    the agents' velocities (a world with a movable landmark also has lvel [L][2][ld])
  *         act  [act_total][ld]  soft one-hot Discrete(5) action per agent (environment.py:188-190),
  *                            [A][5][ld] when every agent is silent; see mpe_buffers
  *         noise[A][2][ld]    standard normals for u_noise (core.py:147); may be NULL (then none, or with
@@ -96,7 +96,7 @@ extern "C" {
 #define MPE_ERR_DESC (-2)        /* descriptor fails mpe_desc_check                  */
 #define MPE_ERR_BATCH (-3)       /* B <= 0 or ld < B                                  */
 #define MPE_ERR_ALIGN (-4)       /* a device pointer is not aligned to its element   */
-#define MPE_ERR_UNSUPPORTED (-5) /* e.g. movable landmarks, non-silent agents        */
+#define MPE_ERR_UNSUPPORTED (-5) /* e.g. movable landmarks outside kinds 0-4         */
 #define MPE_ERR_ARG (-6)         /* any other bad scalar argument                    */
 #define MPE_ERR_SCRATCH (-7)     /* batch needs more than the built-in scratch array (mpe_env_step_stats_static) */
 
@@ -173,6 +173,11 @@ typedef struct mpe_scenario_desc {
   int32_t n_forests;
   uint8_t leader[MPE_MAX_AGENTS];      /* agent.leader (simple_world_comm.py:27,261): sees everybody  */
   double c_noise[MPE_MAX_AGENTS];      /* agent.c_noise; 0 encodes None (core.py:229)                 */
+  /* Movable landmarks (movable[e] != 0 for e >= n_agents; no scenario file of the reference has one, but
+     core.py:211-222 integrates every movable entity): entity.max_speed of entity e >= n_agents, < 0 encodes
+     None; entries of agents are ignored (theirs is max_speed[]).  Such a world needs mpe_buffers.lvel, runs
+     the generic tile kernel, and is accepted for the all-silent stock kinds 0-4 only. */
+  double lm_max_speed[MPE_MAX_ENTITIES];
 } mpe_scenario_desc;
 
 /*
@@ -214,6 +219,9 @@ typedef struct mpe_buffers {
   uint64_t env_id0;                /* global id of env 0 of this call (shards of one batch: their offset) */
   const uint32_t *noise_step_dev;  /* DEVICE word added to noise_step when not NULL: a step recorded in a HIP graph bakes
                                       noise_step, so the part that moves from replay to replay lives in memory */
+  void *lvel;        /* [L][2][ld] velocities of the landmarks (entity.state.p_vel of world.landmarks): required by the
+                        stepping calls when a landmark is movable (updated in place, like vel), zeroed by mpe_reset when
+                        not NULL; ignored otherwise */
 } mpe_buffers;
 
 int mpe_abi_version(void);
@@ -222,7 +230,7 @@ const char *mpe_strerror(int code);
 int64_t mpe_desc_sizeof(void);
 int64_t mpe_buffers_sizeof(void);
 
-/* Validates a descriptor (counts, positive masses/margin, landmarks immovable). */
+/* Validates a descriptor (counts, positive masses/margin, what the kind supports). */
 int mpe_desc_check(const mpe_scenario_desc *desc);
 
 /* Observation geometry == len(scenario.observation(agent, world)) (environment.py:78);

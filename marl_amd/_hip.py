@@ -61,6 +61,7 @@ class ScenarioDesc(C.Structure):
         ('n_food', C.c_int32), ('n_forests', C.c_int32),
         ('leader', C.c_uint8 * MPE_MAX_AGENTS),
         ('c_noise', C.c_double * MPE_MAX_AGENTS),
+        ('lm_max_speed', C.c_double * MPE_MAX_ENTITIES),
     ]
 
 
@@ -69,7 +70,7 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('act', 'noise', 'pos', 'vel', 'comm', 'lforce', 'goal', 'obs', 'rew',
                                           'info', 'stats', 'cnoise')] + [
         ('flags', C.c_uint32), ('noise_step', C.c_uint32), ('noise_seed', C.c_uint64), ('env_id0', C.c_uint64),
-        ('noise_step_dev', C.c_void_p)]
+        ('noise_step_dev', C.c_void_p), ('lvel', C.c_void_p)]
 
     def __init__(self, flags=0, **tensors):
         super().__init__()

@@ -32,8 +32,10 @@ class EntityState(object):
             raise RuntimeError('entity state is only available after World.allocate()')
         if name == 'pos':
             return w.pos[i]
-        if i >= w.vel.shape[0]:
-            return None
+        if i >= w.vel.shape[0]:    # a landmark: it has velocity rows only in a world with a movable landmark
+            if w._landmark_velocities() is None:
+                return None
+            return w.lvel[i - w.vel.shape[0]]
         return w.vel[i]
 
     @property
@@ -187,7 +189,7 @@ class World(object):
         self.ld = 0                # row stride of every SoA buffer (>= num_envs, see padded_stride)
         self.device = None
         self.dtype = None
-        self.pos = self.vel = self.comm = self.act = self.noise = self.lforce = None
+        self.pos = self.vel = self.comm = self.act = self.noise = self.lforce = self.lvel = None
         self.cnoise = None         # optional caller-supplied normals for c_noise, [A, dim_c, B]
         # u_noise / c_noise normals (core.py:147-148,229): `world.noise` / `world.cnoise` when the caller supplies them
         # (recorded draws: parity mode); otherwise drawn INSIDE the step kernels, keyed by (seed, global env id,
@@ -287,6 +289,7 @@ class World(object):
         self.act_rows = self.rows(sum(self.act_dims))
         self.act = self.act_rows.view(A, 5, B) if self._uniform_actions else self.act_rows
         self.lforce = self.rows(A, 2) if any(a.forced_id >= 0 for a in self.agents) else None
+        self.lvel = None           # [L, 2, B] landmark velocities: allocated once a landmark is movable
         self.goal = self.rows(dtype=torch.int32)   # [B]; [goal_rows, B] for scenarios with several goals (set_goal_rows)
         self.noise = None
         self._noise_buf = None
@@ -338,6 +341,15 @@ class World(object):
             if not a.silent:
                 c = torch.as_tensor(action.c, dtype=self.dtype, device=self.device).expand(self.num_envs, self.dim_c)
                 rows[r0:r0 + self.dim_c].copy_(c.t())
+
+    def _landmark_velocities(self):
+        """``world.lvel`` [L, 2, B] when some landmark is movable (no scenario file has one, but core.py:211-222
+        integrates every movable entity; set ``landmark.movable = True`` and call ``world.invalidate_descriptor()``),
+        else None.  Allocated on first need."""
+        if self.lvel is None and any(l.movable for l in self.landmarks):
+            self.lvel = self.rows(len(self.landmarks), 2)
+            self._buf.set(lvel=self.lvel)
+        return self.lvel
 
     def _clean_silent_comm(self):
         """core.py:226-227: a step leaves agent.state.c of a silent agent at zeros(dim_c).  The kernels are told not to
@@ -476,12 +488,15 @@ class World(object):
             raise ValueError('world too large for libmpe_hip (max %d agents / %d entities)'
                              % (_hip.MPE_MAX_AGENTS, _hip.MPE_MAX_ENTITIES))
         d.kind, d.n_agents, d.n_landmarks, d.dim_c = self.hip_kind, A, L, self.dim_c
+        self._landmark_velocities()
         d.dt, d.damping = self.dt, self.damping
         d.contact_force, d.contact_margin = self.contact_force, self.contact_margin
         d.agent_pos_range, d.landmark_pos_range = self.agent_pos_range, self.landmark_pos_range
         for i, e in enumerate(self.entities):
             d.size[i], d.mass[i] = e.size, e.mass
             d.movable[i], d.collide[i] = int(bool(e.movable)), int(bool(e.collide))
+            if i >= A:          # Entity.max_speed of a landmark (core.py:42,217): matters when it is movable
+                d.lm_max_speed[i] = -1.0 if e.max_speed is None else e.max_speed
         d.reward_variant = int(getattr(self, 'reward_variant', 0))
         d.n_target_obs = int(getattr(self, 'n_target_obs', 3))
         for i, a in enumerate(self.agents):

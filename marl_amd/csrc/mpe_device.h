@@ -21,9 +21,10 @@ struct DevDesc {
   int32_t ncol_prefix;  // >= 0: exactly the entities [0, ncol_prefix) collide (fast pair loop); -1: irregular
   T dt, damp1 /* 1 - damping */, cforce, k, inv_k /* RN(1 / k) */;
   T size[MPE_MAX_ENTITIES];
-  T mass[MPE_MAX_AGENTS];
+  T mass[MPE_MAX_ENTITIES];       // agents; landmarks too when one of them is movable
   T accel[MPE_MAX_AGENTS];
-  T max_speed[MPE_MAX_AGENTS];  // < 0: None
+  T max_speed[MPE_MAX_ENTITIES];  // < 0: None; entries >= A: movable landmarks (Entity.max_speed)
+  int32_t lm_movable;             // some landmark is movable: vel rows exist for all E entities (p.lvel)
   T u_noise[MPE_MAX_AGENTS];    // 0: None
   int32_t obs_row0[MPE_MAX_AGENTS];
   uint32_t movable[MPE_MAX_ENTITIES / 32];
@@ -60,6 +61,7 @@ struct KParams {
   const T *act, *noise, *cnoise;
   const int32_t *goal;  // per-env goal landmark index (simple_adversary / simple_push), else unused
   T *pos, *vel, *comm, *lforce, *obs, *rew, *info;
+  T *lvel;  // [L][2][ld] landmark velocities (worlds with a movable landmark), else nullptr
   double *stats;
   int64_t B, ld;
   uint32_t flags;  // mpe_buffers.flags (MPE_FLAG_*): the kernels read MPE_FLAG_SILENT_COMM_ZERO, MPE_FLAG_DEVICE_NOISE

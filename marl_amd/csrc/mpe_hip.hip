@@ -131,7 +131,12 @@ extern "C" int mpe_desc_check(const mpe_scenario_desc *h) {
   const int E = h->n_agents + h->n_landmarks;
   for (int e = 0; e < E; ++e) {
     if (!std::isfinite(h->size[e]) || !(h->mass[e] > 0.0)) return MPE_ERR_DESC;
-    if (e >= h->n_agents && h->movable[e]) return MPE_ERR_UNSUPPORTED;
+    // a movable landmark (core.py:211-222 integrates every movable entity): the all-silent stock kinds, whose
+    // gathers never look at a landmark's velocity
+    if (e >= h->n_agents && h->movable[e]) {
+      if (h->kind > MPE_SIMPLE_PUSH) return MPE_ERR_UNSUPPORTED;
+      if (std::isnan(h->lm_max_speed[e])) return MPE_ERR_DESC;
+    }
   }
   for (int a = 0; a < h->n_agents; ++a)
     if (!std::isfinite(h->accel[a]) || std::isnan(h->max_speed[a]) || !std::isfinite(h->u_noise[a]) ||
@@ -286,6 +291,11 @@ static void to_device_desc(const mpe_scenario_desc *h, DevDesc<T> &d) {
     if (h->movable[e]) d.movable[e >> 5] |= 1u << (e & 31);
     if (h->collide[e]) d.collide[e >> 5] |= 1u << (e & 31);
   }
+  for (int e = d.A; e < d.E; ++e) {
+    d.mass[e] = (T)h->mass[e];
+    d.max_speed[e] = (T)h->lm_max_speed[e];
+    if (h->movable[e]) d.lm_movable = 1;
+  }
   for (int a = 0; a < d.A; ++a) {
     d.mass[a] = (T)h->mass[a];
     d.accel[a] = (T)h->accel[a];
@@ -391,8 +401,15 @@ static SmallId hier_variant(const mpe_scenario_desc *h) {
 
 // The register kernel hard-codes the stock shapes and role flags (mpe_small_kernel.h: which
 // entities collide, who has a max_speed, adversaries first); anything else -> tile kernel.
+static bool any_movable_landmark(const mpe_scenario_desc *h) {
+  for (int e = h->n_agents; e < h->n_agents + h->n_landmarks; ++e)
+    if (h->movable[e]) return true;
+  return false;
+}
+
 static SmallId small_variant(const mpe_scenario_desc *h) {
   const int A = h->n_agents, L = h->n_landmarks;
+  if (any_movable_landmark(h)) return SMALL_NONE;  // the register kernels hard-code fixed landmarks
   SmallId id;
   int nadv, ecol;       // adversaries (first nadv agents), leading colliding entities
   bool has_max;
@@ -488,6 +505,11 @@ static int bind_buffers(const mpe_scenario_desc *h, int64_t B, int64_t ld, const
   p.pos = (T *)b->pos;
   p.vel = (T *)b->vel;
   p.lforce = lf ? (T *)b->lforce : nullptr;
+  if (any_movable_landmark(h)) {  // their velocities: stepped, and nothing observes them in the kinds that allow one
+    if (do_step && !b->lvel) return MPE_ERR_NULL;
+    if (misaligned<T>(b->lvel)) return MPE_ERR_ALIGN;
+    p.lvel = do_step ? (T *)b->lvel : nullptr;
+  }
   if (do_step) {
     p.act = (const T *)b->act;
     p.noise = (const T *)b->noise;
@@ -553,7 +575,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E, int A, int dim_c, double ra,
                                                      double rl, uint32_t k0, uint32_t k1, uint32_t episode,
                                                      uint64_t env_id0, const uint8_t *mask, T *pos, T *vel,
-                                                     T *comm, int32_t *goal, int goal_rows) {
+                                                     T *comm, int32_t *goal, int goal_rows, T *lvel) {
   const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (env >= B) return;
   if (mask != nullptr && mask[env] == 0) return;
@@ -572,6 +594,8 @@ __global__ __launch_bounds__(256) void reset_kernel(int64_t B, int64_t ld, int E
     pos[(int64_t)(2 * e + 1) * ld + env] = (T)uniform_pm(w[2], w[3], r);
   }
   for (int r = 0; r < 2 * A; ++r) vel[(int64_t)r * ld + env] = T(0);
+  if (lvel != nullptr)  // landmark.state.p_vel = zeros (simple_tag.py:54)
+    for (int r = 0; r < 2 * (E - A); ++r) lvel[(int64_t)r * ld + env] = T(0);
   if (comm != nullptr)
     for (int r = 0; r < A * dim_c; ++r) comm[(int64_t)r * ld + env] = T(0);
 }
@@ -584,14 +608,15 @@ static int reset_impl(const mpe_scenario_desc *h, int64_t B, int64_t ld, uint64_
   if (!b || !b->pos || !b->vel) return MPE_ERR_NULL;
   T *pos = (T *)b->pos, *vel = (T *)b->vel, *comm = (T *)b->comm;
   int32_t *goal = b->goal;
-  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm) || misaligned<int32_t>(goal))
+  if (misaligned<T>(pos) || misaligned<T>(vel) || misaligned<T>(comm) || misaligned<int32_t>(goal) ||
+      misaligned<T>(b->lvel))
     return MPE_ERR_ALIGN;
   if (h->n_landmarks < 1 || goal_rows_of(h) < 1) goal = nullptr;
   const dim3 grid((unsigned)((B + 255) / 256)), block(256);
   hipLaunchKernelGGL(reset_kernel<T>, grid, block, 0, (hipStream_t)stream, B, ld,
                      h->n_agents + h->n_landmarks, h->n_agents, h->dim_c, h->agent_pos_range,
                      h->landmark_pos_range, (uint32_t)seed, (uint32_t)(seed >> 32), episode, env_id0, mask, pos,
-                     vel, comm, goal, goal_rows_of(h));
+                     vel, comm, goal, goal_rows_of(h), (T *)b->lvel);
   return (int)hipGetLastError();
 }
 

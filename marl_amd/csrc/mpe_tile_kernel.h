@@ -412,8 +412,48 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           sVel[(2 * a + 1) * TILE + lane] = vy;
         }
       }
+      // movable landmarks (no scenario file has one; core.py:211-222 integrates every movable entity): damped, pushed by
+      // the colliding entities BEHIND them (one-sided response: pairs (e, b > e), i.e. later landmarks only), clamped,
+      // moved.  Their velocity rows follow the agents' in LDS.
+      if (!LGLOB && d.lm_movable) {
+        for (int e = A + chunk; e < E; e += NCH) {
+          if (!bit(d.movable, e)) continue;
+          T vx = ld_state(p.lvel + (int64_t)(2 * (e - A)) * ld + ge), vy = ld_state(p.lvel + (int64_t)(2 * (e - A) + 1) * ld + ge);
+          T Fx = T(0), Fy = T(0);
+          if (bit(d.collide, e)) {
+            const T pex = sPos[(2 * e) * TILE + lane], pey = sPos[(2 * e + 1) * TILE + lane];
+            for (int b = e + 1; b < E; ++b) {
+              if (!bit(d.collide, b)) continue;
+              T fx, fy;
+              pair_force<T>(pex - sPos[(2 * b) * TILE + lane], pey - sPos[(2 * b + 1) * TILE + lane], d.size[e] + d.size[b],
+                            d, fx, fy);
+              Fx = fx + Fx;
+              Fy = fy + Fy;
+            }
+          }
+          integrate_vel<T>(vx, vy, Fx, Fy, d.mass[e], d.damp1, d.dt, d.max_speed[e]);
+          if (active) {
+            st_state(p.lvel + (int64_t)(2 * (e - A)) * ld + env, vx);
+            st_state(p.lvel + (int64_t)(2 * (e - A) + 1) * ld + env, vy);
+          }
+          sVel[(2 * e) * TILE + lane] = vx;
+          sVel[(2 * e + 1) * TILE + lane] = vy;
+        }
+      }
       __syncthreads();
       // ---- phase 2: positions (core.py:222), comm (core.py:226-227) -----------------------------
+      if (!LGLOB && d.lm_movable) {
+        for (int e = A + chunk; e < E; e += NCH) {
+          if (!bit(d.movable, e)) continue;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int r = 2 * e + c;
+            const T np_ = sPos[r * TILE + lane] + sVel[r * TILE + lane] * d.dt;
+            sPos[r * TILE + lane] = np_;
+            if (active) st_state(p.pos + (int64_t)r * ld + env, np_);
+          }
+        }
+      }
       for (int a = chunk; a < A; a += NCH) {
         if (bit(d.movable, a)) {
 #pragma unroll
@@ -1121,7 +1161,9 @@ inline size_t tile_lds_bytes(const mpe_scenario_desc *h, int threads) {
   const int E = h->n_agents + h->n_landmarks;
   size_t aux = h->kind == MPE_SIMPLE_TAG ? (size_t)(NCH + h->n_agents) * TILE * sizeof(int)
                                          : (size_t)h->n_landmarks * TILE * sizeof(T);  // hierarchy: A ints < vel rows
-  size_t velb = (size_t)(2 * h->n_agents) * TILE * sizeof(T);
+  bool lm_moves = false;  // a movable landmark: velocity rows for every entity
+  for (int e = h->n_agents; e < E; ++e) lm_moves = lm_moves || h->movable[e];
+  size_t velb = (size_t)(2 * (lm_moves ? E : h->n_agents)) * TILE * sizeof(T);
   if (velb < aux) velb = aux;
   size_t lfb = 0;
   for (int a = 0; a < h->n_agents; ++a)

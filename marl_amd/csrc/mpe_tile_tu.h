@@ -57,7 +57,9 @@ static int launch_tile(const mpe_scenario_desc *h, const KParams<T> &p, hipStrea
     // worlds whose full tile leaves room for fewer than four workgroups per CU keep the landmarks in global memory
     // (mpe_tile_kernel.h: LGLOB): the fused step only, f32 (the f64 tile is 32 envs: half the bytes per row already)
     if constexpr (DO_STEP && DO_OBS && sizeof(T) == 4) {
-      if (h->n_landmarks > 0 && tile_lds_bytes<T>(h, THREADS) > 40 * 1024)
+      bool fixed = h->n_landmarks > 0;  // (a movable landmark cannot stay in global memory: its row changes under the pair loops)
+      for (int e = h->n_agents; e < h->n_agents + h->n_landmarks; ++e) fixed = fixed && !h->movable[e];
+      if (fixed && tile_lds_bytes<T>(h, THREADS) > 40 * 1024)
         return launch_tile_k<T, MPE_LGLOB_THREADS, DO_STEP, DO_OBS, false, MPE_SIMPLE_TAG, true>(h, p, s);
     }
 #endif

@@ -31,7 +31,7 @@ class CapturedSteps(object):
         # everything a step moves: the warm-up step and the capture itself (which executes nothing, but runs the host
         # side of K steps) must leave the world exactly as it was, also when the capture fails
         state = [None if t is None else t.clone()
-                 for t in (w.pos, w.vel, w.lforce, w.stats, w.comm if w._comm_arg is not None else None)]
+                 for t in (w.pos, w.vel, w.lforce, w.stats, w.comm if w._comm_arg is not None else None, w.lvel)]
         host = (w._obs_slot, w.act, w.noise_step, w._gather_tick)
         try:
             env.step(self.actions[0])              # every lazy one-time cost (module load, LDS limit) before the capture
@@ -52,7 +52,7 @@ class CapturedSteps(object):
 
     def _restore(self, state, host):
         w = self.env.world
-        for t, saved in zip((w.pos, w.vel, w.lforce, w.stats, w.comm), state):
+        for t, saved in zip((w.pos, w.vel, w.lforce, w.stats, w.comm, w.lvel), state):
             if saved is not None and t is not None:
                 t.copy_(saved)
         w._obs_slot, w.act, w.noise_step, gather_tick = host

@@ -40,7 +40,7 @@ class HipScenario(BaseScenario):
         # agent.state.c = zeros(dim_c) (simple_tag.py:51): the rows of silent agents hold zeros already (World.allocate,
         # World._clean_silent_comm), so only a world in which somebody speaks has anything to clear
         world._clean_silent_comm()
-        b = _hip.Buffers(pos=world.pos, vel=world.vel, comm=world._comm_arg,
+        b = _hip.Buffers(pos=world.pos, vel=world.vel, comm=world._comm_arg, lvel=world.lvel,
                          goal=world.goal if world.hip_kind in _hip.GOAL_KINDS else None)
         with _hip.on_device(world.device):
             _hip.check(fn(d, world.num_envs, world.ld, world.seed, world.episode, world.env_id0,

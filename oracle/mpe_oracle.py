@@ -87,6 +87,9 @@ class ScenarioSpec:
     n_forests: int = 0
     leader: Optional[Sequence[bool]] = None          # agent.leader (simple_world_comm.py:27): sees through forests
     c_noise: Optional[Sequence[Optional[float]]] = None   # per agent (core.py:74,229); None -> no comm noise
+    # movable landmarks (no scenario file has one; core.py:211-222 integrates EVERY movable entity): max_speed per
+    # LANDMARK (Entity.max_speed, core.py:42); movable / mass / collide come from the per-entity lists above
+    landmark_max_speed: Optional[Sequence[Optional[float]]] = None
 
     def __post_init__(self):
         A = self.n_agents
@@ -106,6 +109,8 @@ class ScenarioSpec:
             self.leader = [False] * A
         if self.c_noise is None:
             self.c_noise = [None] * A
+        if self.landmark_max_speed is None:
+            self.landmark_max_speed = [None] * self.n_landmarks
         if self.advfollower is None:                 # L1F2_3Targets_100observe.py:40,52,64: the silent adversaries
             self.advfollower = [bool(self.adversary[i]) and not self.advleader[i] and self.kind in (HIER_PURSUIT, HIER_MOVING)
                                 for i in range(A)]
@@ -340,7 +345,7 @@ class SerialEnv:
             b.adversary = bool(spec.adversary[e]) if b.is_agent else False
             b.size = spec.size[e]
             b.accel = spec.accel[e] if b.is_agent else None
-            b.max_speed = spec.max_speed[e] if b.is_agent else None
+            b.max_speed = spec.max_speed[e] if b.is_agent else spec.landmark_max_speed[e - spec.n_agents]
             b.collide = bool(spec.collide[e])
             b.movable = bool(spec.movable[e])
             b.u_noise = spec.u_noise[e] if b.is_agent else None
@@ -373,11 +378,14 @@ class SerialEnv:
         self.discrete_action_space = True    # environment.py:29; False: the action IS the force command (:191-192)
 
     # -- state helpers ----------------------------------------------------------------
-    def set_state(self, pos, vel):
+    def set_state(self, pos, vel, lvel=None):
         for e, b in enumerate(self.bodies):
             b.pos = np.array(pos[e], dtype=np.float64)
         for i, a in enumerate(self.agents):
             a.vel = np.array(vel[i], dtype=np.float64)
+        if lvel is not None:             # movable landmarks carry a velocity too (core.py:211-222)
+            for i, lm in enumerate(self.landmarks):
+                lm.vel = np.array(lvel[i], dtype=np.float64)
 
     def get_state(self):
         return (np.stack([b.pos for b in self.bodies]), np.stack([a.vel for a in self.agents]))
@@ -1019,14 +1027,21 @@ class BatchedOracle:
                 lf[i] = lf[i] + f
         return lf
 
-    def world_step(self, pos, vel, act, noise=None, return_lforce=False, scripted_u=None):
+    def world_step(self, pos, vel, act, noise=None, return_lforce=False, scripted_u=None, lvel=None):
         """act: [A,5,B] (all agents silent) or ragged rows [sum(act_dims), B] (environment.py:161-168).
         scripted_u: {agent index: u [2, B]} for agents with an action_callback (core.py:126-127): the force as the
-        callback returned it, no sensitivity; their action rows are not looked at."""
+        callback returned it, no sensitivity; their action rows are not looked at.
+        lvel: [L,2,B] velocities of the landmarks (worlds with a movable landmark); then returns (pos, vel, lvel)."""
         s, T = self.spec, self.dt
         A, E = s.n_agents, s.n_entities
         pos = np.array(pos, dtype=T)
         vel = np.array(vel, dtype=T)
+        if lvel is not None:
+            assert not return_lforce
+            vel = np.concatenate([vel, np.array(lvel, dtype=T)], 0)      # per entity from here on
+        else:
+            assert not any(s.movable[A:]), 'a movable landmark needs lvel'
+        ms_all = list(s.max_speed) + list(s.landmark_max_speed)
         act = np.asarray(act, dtype=T)
         if act.ndim == 3:
             act = act.reshape(-1, act.shape[-1])
@@ -1068,8 +1083,8 @@ class BatchedOracle:
                 v = vel[i] * T(1 - s.damping)
                 if force[i] is not None:
                     v = v + (force[i] / T(s.mass[i])) * T(s.dt)
-                if i < A and s.max_speed[i] is not None:
-                    ms = T(s.max_speed[i])
+                if ms_all[i] is not None:
+                    ms = T(ms_all[i])
                     speed = np.sqrt(np.square(v[0]) + np.square(v[1]))
                     clamped = v / speed * ms
                     v = np.where(speed > ms, clamped, v)
@@ -1077,6 +1092,8 @@ class BatchedOracle:
                 pos[i] = pos[i] + v * T(s.dt)
         if return_lforce:
             return pos, vel, (lforce if lforce is not None else np.zeros((A, 2, pos.shape[-1]), T))
+        if lvel is not None:
+            return pos, vel[:A], vel[A:]
         return pos, vel
 
     def comm_state(self, act, cnoise=None):
@@ -1487,7 +1504,11 @@ class BatchedOracle:
                     info[i, 0], info[i, 1], info[i, 2], info[i, 3] = r, c, md, occ
         return obs, rew, (info if want_info else None)
 
-    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False, cnoise=None, scripted_u=None):
+    def env_step(self, pos, vel, act, noise=None, goal=None, return_lforce=False, cnoise=None, scripted_u=None, lvel=None):
+        if lvel is not None:             # a world with a movable landmark: returns (..., info, lvel)
+            pos, vel, lvel = self.world_step(pos, vel, act, noise, scripted_u=scripted_u, lvel=lvel)
+            obs, rew, info = self.observe(pos, vel, goal=goal)
+            return pos, vel, obs, rew, info, lvel
         pos, vel, lforce = self.world_step(pos, vel, act, noise, return_lforce=True, scripted_u=scripted_u)
         obs, rew, info = self.observe(pos, vel, goal=goal, lforce=lforce,
                                       comm=self.comm_state(act, cnoise) if self.spec.kind in COMM_KINDS + (SIMPLE_CRYPTO, WORLD_COMM) else None)

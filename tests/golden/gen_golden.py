@@ -646,6 +646,7 @@ def main():
         save('m_' + name + '_dense', **rollout_hier(name, range(24), 25, init=dense_init))
         save('m_' + name + '_crowd', **rollout_hier(name, range(16), 6, init=crowd_init))
     hier_rest()
+    movable_cases()
     discrete_cases()
     scripted_cases()
     kat_cases()
@@ -672,6 +673,67 @@ def discrete_cases():
     continuous_cases()
 
 
+def rollout_movable_landmarks(kind, seeds, T, tweak, init=None):
+    """A stock world in which `tweak(world)` made some landmarks movable (Entity.movable / mass / max_speed, core.py:36-53;
+    no scenario file does): core.py:211-222 integrates every movable entity, so the landmarks get a velocity ('lvel',
+    recorded per step), are damped, and are pushed by the landmarks behind them (one-sided response, core.py:199-208)."""
+    keys = ('pos0', 'vel0', 'lvel0', 'act', 'pos', 'vel', 'lvel', 'obs', 'rew')
+    out = {k: [] for k in keys}
+    for seed in seeds:
+        env, world = build_env(kind, seed)
+        tweak(world)
+        A = len(world.agents)
+        env.reset()
+        if init is not None:
+            init(world, np.random.RandomState(10_000 + seed))
+        lv = np.random.RandomState(40_000 + seed).uniform(-0.5, 0.5, size=(len(world.landmarks), 2))
+        for lm, v in zip(world.landmarks, lv):
+            lm.state.p_vel = v.copy() if lm.movable else np.zeros(2)
+        pos0, vel0 = _state(world)
+        out['lvel0'].append(np.stack([lm.state.p_vel for lm in world.landmarks]).astype(np.float64))
+        arng = np.random.RandomState(20_000 + seed)
+        ep = {k: [] for k in ('act', 'pos', 'vel', 'lvel', 'obs', 'rew')}
+        for t in range(T):
+            act = arng.rand(A, 5)
+            obs_n, rew_n, done_n, info_n = env.step([act[i].copy() for i in range(A)])
+            pos, vel = _state(world)
+            ep['act'].append(act)
+            ep['pos'].append(pos.copy())
+            ep['vel'].append(vel.copy())
+            ep['lvel'].append(np.stack([lm.state.p_vel for lm in world.landmarks]).astype(np.float64))
+            ep['obs'].append(np.concatenate(obs_n))
+            ep['rew'].append(np.asarray(rew_n, dtype=np.float64))
+        out['pos0'].append(pos0)
+        out['vel0'].append(vel0)
+        for k in ep:
+            out[k].append(np.stack(ep[k]))
+    res = {k: np.stack(v) for k, v in out.items()}
+    res['seeds'] = np.asarray(list(seeds))
+    return res
+
+
+def _tag_movable(world):          # both landmarks move; the second one is heavy and speed-limited
+    world.landmarks[0].movable = True
+    world.landmarks[1].movable = True
+    world.landmarks[1].initial_mass = 2.5
+    world.landmarks[1].max_speed = 0.08
+
+
+def _spread_movable(world):       # landmarks 0 and 2 move and (unlike the stock file) collide: 0 is pushed by 1 and 2
+    for i in (0, 2):
+        world.landmarks[i].movable = True
+    for lm in world.landmarks:
+        lm.collide = True
+        lm.size = 0.12
+    world.landmarks[2].max_speed = 0.3
+
+
+def movable_cases():
+    save('g19_simple_tag_movable_landmarks', **rollout_movable_landmarks('simple_tag', range(16), 25, _tag_movable, init=dense_init))
+    save('g19_simple_spread_movable_landmarks', **rollout_movable_landmarks('simple_spread', range(16), 25, _spread_movable,
+                                                                           init=dense_init))
+
+
 def continuous_cases():
     """env.discrete_action_space = False (environment.py:191-192, "NEVER do here" in the fork's comments but a live
     switch): 'act'[:, :, :, 0:2] holds the force command u that was passed to env.step."""
@@ -693,6 +755,8 @@ if __name__ == '__main__':
         discrete_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == 'continuous':
         continuous_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'movable':
+        movable_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == 'scripted':
         scripted_cases()
     else:

@@ -57,6 +57,7 @@ class HipSim:
         self.goal = torch.zeros(max(spec.goal_rows, 1), self.ld, dtype=torch.int32, device='cuda')
         self.lforce = torch.zeros(A, 2, self.ld, **z) if spec.has_leader_force else None
         self.comm = torch.full((A, max(spec.dim_c, 1), self.ld), float('nan'), **z)[:, :spec.dim_c]
+        self.lvel = torch.zeros(E - A, 2, self.ld, **z) if any(spec.movable[A:]) else None
         self.stream = torch.cuda.current_stream().cuda_stream
 
     def set_state(self, pos, vel, goal=None, lforce=None):
@@ -73,7 +74,8 @@ class HipSim:
     def buffers(self, device_noise=None, **kw):
         """mpe_buffers with the state members set, plus the given tensors.  device_noise = (seed, step, env_id0[,
         int32 device tensor added to step]): MPE_FLAG_DEVICE_NOISE with those key words."""
-        b = _hip.Buffers(flags=call_flags(), pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal, **kw)
+        b = _hip.Buffers(flags=call_flags(), pos=self.pos, vel=self.vel, lforce=self.lforce, goal=self.goal,
+                         lvel=self.lvel, **kw)
         if device_noise is not None:
             b.flags |= _hip.FLAG_DEVICE_NOISE
             b.noise_seed, b.noise_step, b.env_id0 = device_noise[:3]

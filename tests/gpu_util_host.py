@@ -24,6 +24,9 @@ def desc_from_spec(spec):
         d.advfollower[a] = int(spec.advfollower[a])
         d.leader[a] = int(spec.leader[a])
         d.c_noise[a] = spec.c_noise[a] if spec.c_noise[a] else 0.0
+    for l in range(spec.n_landmarks):
+        ms = spec.landmark_max_speed[l]
+        d.lm_max_speed[spec.n_agents + l] = -1.0 if ms is None else ms
     d.n_food, d.n_forests = spec.n_food, spec.n_forests
     d.reward_variant, d.n_target_obs = spec.reward_variant, spec.n_target_obs
     assert _hip.lib.mpe_desc_check(d) == 0

@@ -7,6 +7,7 @@ Bars (BASELINE.json north_star):
   f32: <= 1e-4 relative (atol 1e-4 for quantities near zero); rewards / collision counts equal
        except on envs within 1e-5 of a collision / bound() threshold.
 """
+import dataclasses
 import os
 
 import numpy as np
@@ -486,8 +487,8 @@ def test_c_abi_rejects_bad_arguments():
     d.n_agents = 100
     assert f(d, 8, 8, sim.buffers(**good), sim.stream) == -2
     d = type(sim.desc).from_buffer_copy(sim.desc)
-    d.movable[5] = 1
-    assert f(d, 8, 8, sim.buffers(**good), sim.stream) == -5
+    d.movable[5] = 1                                                      # a movable landmark needs buffers.lvel
+    assert f(d, 8, 8, sim.buffers(**good), sim.stream) == -1
     torch.cuda.synchronize()
 
 
@@ -512,3 +513,76 @@ def test_episode_stats_of_the_goal_scenarios(mk, force_tile):
     assert lib.mpe_stats_reduce(stats.data_ptr(), rows, W, out.data_ptr(), sim.stream) == 0
     torch.testing.assert_close(out[:A], want, rtol=1e-12, atol=1e-9)
     assert out[2 * A + 1].item() == 4 * B
+
+
+MOVABLE = [('g19_simple_tag_movable_landmarks',
+            lambda: dataclasses.replace(O.simple_tag_spec(), movable=[True] * 6, mass=[1, 1, 1, 1, 1, 2.5],
+                                        landmark_max_speed=[None, 0.08])),
+           ('g19_simple_spread_movable_landmarks',
+            lambda: dataclasses.replace(O.simple_spread_spec(), movable=[True] * 3 + [True, False, True], collide=[True] * 6,
+                                        size=[0.15] * 3 + [0.12] * 3, landmark_max_speed=[None, None, 0.3]))]
+
+
+@pytest.mark.parametrize('name,mk', MOVABLE)
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=['f64', 'f32'])
+def test_movable_landmarks_match_reference(golden_dir, name, mk, dtype, tol):
+    """core.py:211-222 integrates EVERY movable entity: a landmark made movable (no scenario file does; fixtures G19
+    generated from the reference with Entity.movable / initial_mass / max_speed set on landmarks) gets a velocity, is
+    damped, pushed by the colliding landmarks behind it (one-sided response), speed-clamped and moved.  Such worlds run
+    the generic tile kernel.  f64 free-running within 1e-9, f32 teacher-forced within 1e-4; split entry points == fused."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    sim, two = HipSim(spec, S, dtype), HipSim(spec, S, dtype)
+    for s_ in (sim, two):
+        s_.set_state(golden_soa(g, 'pos0'), golden_soa(g, 'vel0'))
+        s_.lvel.copy_(dev(golden_soa(g, 'lvel0'), dtype))
+    for t in range(T):
+        if dtype == torch.float32 and t:
+            for s_ in (sim, two):
+                s_.set_state(golden_soa(g, 'pos', t - 1), golden_soa(g, 'vel', t - 1))
+                s_.lvel.copy_(dev(golden_soa(g, 'lvel', t - 1), dtype))
+        act = dev(golden_soa(g, 'act', t), dtype)
+        sim.env_step(act)
+        two.world_step(act)
+        two.observe()
+        pos, vel, obs, rew, info = sim.host()
+        np.testing.assert_allclose(pos, golden_soa(g, 'pos', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(vel, golden_soa(g, 'vel', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(sim.lvel.double().cpu().numpy(), golden_soa(g, 'lvel', t), rtol=tol, atol=tol)
+        np.testing.assert_allclose(obs, g['obs'][:, t].T, rtol=tol, atol=tol)
+        if dtype == torch.float64:
+            np.testing.assert_allclose(rew, golden_soa(g, 'rew', t), rtol=0, atol=tol)
+        for a, b in zip(sim.host(), two.host()):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert torch.equal(sim.lvel, two.lvel)
+    # reset clears the landmark velocities (simple_tag.py:54), untouched rows of an immovable landmark stay zero
+    sim.reset(3, 0)
+    assert not sim.lvel.any() and not sim.vel.any()
+
+
+def test_movable_landmark_through_the_public_api(golden_dir):
+    """landmark.movable = True after make_env (+ world.invalidate_descriptor()): landmark.state.p_vel becomes a view of
+    world.lvel, the trajectory is the reference's."""
+    from marl_amd import make_env
+    g = _load(golden_dir, 'g19_simple_tag_movable_landmarks')
+    S, T = g['act'].shape[:2]
+    env = make_env('simple_tag', num_envs=S, dtype=torch.float64, seed=2)
+    w = env.world
+    assert w.landmarks[0].state.p_vel.shape == (S, 2) and w.lvel is None
+    w.landmarks[0].movable = w.landmarks[1].movable = True
+    w.landmarks[1].initial_mass, w.landmarks[1].max_speed = 2.5, 0.08
+    w.invalidate_descriptor()
+    env.reset()
+    assert w.lvel is not None and not w.lvel.any()
+    w.pos.copy_(dev(golden_soa(g, 'pos0'), torch.float64))
+    w.vel.copy_(dev(golden_soa(g, 'vel0'), torch.float64))
+    for i, lm in enumerate(w.landmarks):
+        lm.state.p_vel = dev(g['lvel0'][:, i], torch.float64)
+    w.mark_dirty()
+    for t in range(T):
+        obs_n, rew_n, _, _ = env.step([dev(g['act'][:, t, i], torch.float64) for i in range(env.n)])
+        np.testing.assert_allclose(w.pos.cpu().numpy(), golden_soa(g, 'pos', t), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(torch.stack([lm.state.p_vel for lm in w.landmarks]).cpu().numpy(),
+                                   np.moveaxis(g['lvel'][:, t], 0, 1), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(torch.cat(obs_n, 1).cpu().numpy(), g['obs'][:, t], rtol=0, atol=1e-9)

@@ -78,8 +78,12 @@ def test_descriptor_validation_and_error_codes():
     assert lib.mpe_desc_check(bad) == -2
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.kind = 11
     assert lib.mpe_desc_check(bad) == -5
-    bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.movable[4] = 1
-    assert lib.mpe_desc_check(bad) == -5
+    ok = _hip.ScenarioDesc.from_buffer_copy(d); ok.movable[4] = 1          # a movable landmark: stock silent kinds only
+    assert lib.mpe_desc_check(ok) == 0
+    bad = _hip.ScenarioDesc.from_buffer_copy(ok); bad.lm_max_speed[4] = float('nan')
+    assert lib.mpe_desc_check(bad) == -2
+    hd = _desc(_hier_spec()); hd.movable[hd.n_agents] = 1
+    assert lib.mpe_desc_check(hd) == -5
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.contact_margin = 0.0
     assert lib.mpe_desc_check(bad) == -2
     bad = _hip.ScenarioDesc.from_buffer_copy(d); bad.mass[1] = 0.0

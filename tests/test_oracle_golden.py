@@ -3,6 +3,8 @@ itself (tests/golden/gen_golden.py).  Bit-exact: the oracle repeats the referenc
 operations in the reference's order."""
 import os
 
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -611,6 +613,49 @@ def test_oracle_continuous_action_space_bit_exact(golden_dir, name, mk, forced):
     if forced:
         u = g['act'][..., :2]
         assert (u[..., 0] == u[..., 1]).any()                           # ties: the first maximum decides
+
+
+MOVABLE_CASES = [('g19_simple_tag_movable_landmarks',
+                  lambda: dataclasses.replace(O.simple_tag_spec(), movable=[True] * 6, mass=[1, 1, 1, 1, 1, 2.5],
+                                              landmark_max_speed=[None, 0.08])),
+                 ('g19_simple_spread_movable_landmarks',
+                  lambda: dataclasses.replace(O.simple_spread_spec(), movable=[True] * 3 + [True, False, True],
+                                              collide=[True] * 6, size=[0.15] * 3 + [0.12] * 3,
+                                              landmark_max_speed=[None, None, 0.3]))]
+
+
+@pytest.mark.parametrize('name,mk', MOVABLE_CASES)
+def test_oracle_movable_landmarks_bit_exact(golden_dir, name, mk):
+    """core.py:211-222 on movable LANDMARKS (fixtures generated from the reference with Entity.movable / initial_mass /
+    max_speed set on landmarks; no scenario file does): both oracle forms reproduce positions, agent and landmark
+    velocities, observations and rewards bit for bit; the speed clamp and landmark-landmark pushes fire."""
+    g = _load(golden_dir, name)
+    spec = mk()
+    S, T = g['act'].shape[:2]
+    bo = O.BatchedOracle(spec)
+    mv = lambda a: np.ascontiguousarray(np.moveaxis(a, 0, -1))
+    pos, vel, lvel = mv(g['pos0']), mv(g['vel0']), mv(g['lvel0'])
+    for t in range(T):
+        pos, vel, obs, rew, info, lvel = bo.env_step(pos, vel, mv(g['act'][:, t]), lvel=lvel)
+        assert np.array_equal(pos, mv(g['pos'][:, t])) and np.array_equal(vel, mv(g['vel'][:, t])), (name, t)
+        assert np.array_equal(lvel, mv(g['lvel'][:, t])), (name, t)
+        assert np.array_equal(np.concatenate(obs, 0), g['obs'][:, t].T) and np.array_equal(rew, g['rew'][:, t].T)
+    for s in range(3):
+        env = O.SerialEnv(spec, benchmark=True)
+        env.set_state(g['pos0'][s], g['vel0'][s], g['lvel0'][s])
+        for t in range(T):
+            obs_n, rew_n, _, _ = env.step([a.copy() for a in g['act'][s, t]])
+            p, v = env.get_state()
+            assert np.array_equal(p, g['pos'][s, t]) and np.array_equal(v, g['vel'][s, t]), (name, s, t)
+            assert np.array_equal(np.stack([lm.vel for lm in env.landmarks]), g['lvel'][s, t])
+            assert np.array_equal(np.concatenate(obs_n), g['obs'][s, t])
+    lv = g['lvel']
+    moved = np.abs(g['pos'][:, -1, spec.n_agents:] - g['pos0'][:, spec.n_agents:]).max(axis=(0, 2))
+    assert all((m > 0) == bool(spec.movable[spec.n_agents + i]) for i, m in enumerate(moved))   # only the movable ones moved
+    ms = [m for m in spec.landmark_max_speed if m is not None][0]
+    l = [i for i, m in enumerate(spec.landmark_max_speed) if m is not None][0]
+    sp = np.sqrt((lv[:, :, l] ** 2).sum(-1))
+    assert sp.max() <= ms * (1 + 1e-12) and (np.abs(sp - ms) < 1e-12).any()                     # the clamp fired
 
 
 def test_device_normals_are_standard_normal_and_keyed_by_global_env_id():
