@@ -91,6 +91,10 @@ def random_spec(rng):
         rep['collide'] = [bool(pick(0.6)) for _ in range(E)]
     if pick(0.4):
         rep['u_noise'] = [None if pick(0.5) else float(rng.uniform(0.05, 0.5)) for _ in range(A)]
+    if kind != 'wcomm' and spec.n_landmarks and pick(0.3):
+        # movable landmarks (core.py:211-222; no scenario file has one): some of them, some with a max_speed
+        rep['movable'] = [True] * A + [bool(pick(0.6)) for _ in range(E - A)]
+        rep['landmark_max_speed'] = [None if pick(0.5) else float(rng.uniform(0.05, 1.0)) for _ in range(E - A)]
     if pick(0.4):
         rep.update(damping=float(rng.uniform(0.0, 0.5)), dt=float(rng.uniform(0.05, 0.2)),
                    contact_force=float(rng.uniform(20, 200)), contact_margin=float(10 ** rng.uniform(-3, -2)))
@@ -113,6 +117,8 @@ def run(n_worlds, seed, perturb=0.0):
         A, E = spec.n_agents, spec.n_entities
         pos = rng.uniform(-0.45, 0.45, (E, 2, B))
         vel = rng.uniform(-0.8, 0.8, (A, 2, B))
+        lm_moves = any(spec.movable[A:])
+        lvel0 = rng.uniform(-0.8, 0.8, (E - A, 2, B)) * np.asarray(spec.movable[A:], float)[:, None, None] if lm_moves else None
         goal = rng.randint(0, max(spec.n_landmarks, 1), B)
         hier = spec.kind == O.HIER_PURSUIT
         ragged = hier or spec.kind == O.WORLD_COMM
@@ -127,14 +133,18 @@ def run(n_worlds, seed, perturb=0.0):
             try:
                 sim = HipSim(spec, B, torch.float64)
                 sim.set_state(pos, vel, goal, lf0)
-                p, v = pos, vel
+                if lm_moves:
+                    sim.lvel.copy_(dev(lvel0, torch.float64))
+                p, v, lv = pos, vel, lvel0
                 for t in range(T):
                     sim.env_step(dev(acts[t], torch.float64), dev(noises[t], torch.float64) if has_noise else None)
-                    p, v, obs, rew, info = bo.env_step(p, v, acts[t], noises[t] if has_noise else None,
-                                                       goal=goal if spec.kind in O.GOAL_KINDS else None)
-                    got = sim.host()
-                    want = (p, v, np.concatenate(obs, 0), rew, info)
-                    for nm, x, y in zip(('pos', 'vel', 'obs', 'rew', 'info'), got, want):
+                    res = bo.env_step(p, v, acts[t], noises[t] if has_noise else None,
+                                      goal=goal if spec.kind in O.GOAL_KINDS else None, lvel=lv)
+                    p, v, obs, rew, info = res[:5]
+                    lv = res[5] if lm_moves else None
+                    got = sim.host() + ((sim.lvel.cpu().numpy(),) if lm_moves else ())
+                    want = (p, v, np.concatenate(obs, 0), rew, info) + ((lv,) if lm_moves else ())
+                    for nm, x, y in zip(('pos', 'vel', 'obs', 'rew', 'info', 'lvel'), got, want):
                         if y is None or x.size == 0:
                             continue
                         y = np.asarray(y, np.float64).reshape(x.shape)
@@ -153,11 +163,13 @@ def run(n_worlds, seed, perturb=0.0):
                 set_call_flags(0)
         # f32 (its own arithmetic and, in the tile kernel, its own pair-loop shape): ONE step from the same state; the
         # continuous outputs within 1e-4 of the f64 oracle (observations only where they carry no visibility masks)
-        p1, v1, obs1, _, _ = bo.env_step(pos, vel, acts[0], noises[0] if has_noise else None,
-                                         goal=goal if spec.kind in O.GOAL_KINDS else None)
+        p1, v1, obs1 = bo.env_step(pos, vel, acts[0], noises[0] if has_noise else None,
+                                   goal=goal if spec.kind in O.GOAL_KINDS else None, lvel=lvel0)[:3]
         if not perturb and np.isfinite(p1).all():
             sim = HipSim(spec, B, torch.float32)
             sim.set_state(pos, vel, goal, lf0)
+            if lm_moves:
+                sim.lvel.copy_(dev(lvel0, torch.float32))
             sim.env_step(dev(acts[0], torch.float32), dev(noises[0], torch.float32) if has_noise else None)
             gp, gv, go, _, _ = sim.host()
             checks = [('pos', gp, p1), ('vel', gv, v1)]
@@ -169,8 +181,9 @@ def run(n_worlds, seed, perturb=0.0):
             scale = max(1.0, float(np.abs(v1).max()))
             # ... and no worse than a few times what the same operations in numpy float32 lose on this world (the speed
             # clamp turns a cancellation error of the force into an error of the direction, whatever |v| is)
-            p32, v32, _, _, _ = O.BatchedOracle(spec, np.float32).env_step(
-                pos, vel, acts[0], noises[0] if has_noise else None, goal=goal if spec.kind in O.GOAL_KINDS else None)
+            p32, v32 = O.BatchedOracle(spec, np.float32).env_step(
+                pos, vel, acts[0], noises[0] if has_noise else None, goal=goal if spec.kind in O.GOAL_KINDS else None,
+                lvel=lvel0)[:2]
             slack = 8.0 * max(float(np.nanmax(np.abs(np.asarray(v32, np.float64) - v1))),
                               float(np.nanmax(np.abs(np.asarray(p32, np.float64) - p1))))
             for nm, x, y in checks:
