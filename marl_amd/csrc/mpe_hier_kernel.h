@@ -22,6 +22,15 @@ namespace mpe {
 #define MPE_HIER_LDS_TARGETS 10
 #endif
 constexpr int kHierLdsTargets = MPE_HIER_LDS_TARGETS;  // worlds with at least this many targets keep them in LDS
+// The per-target loops of the LDS form are REAL loops in f64 (the targets are addressed by index in LDS, their sizes by
+// index in the kernel arguments): the 5-agent / 10-target kernel shrinks from 16 013 to 8 315 instructions (128 -> 66 KB of
+// code streamed once per wavefront) and from 470 to 457 us.  f32 keeps them unrolled (rolled: 191 -> 202 us; its body is a
+// quarter as long and the loop overhead shows).  -DMPE_HIER_UNROLL_TARGETS: unrolled everywhere.
+#ifdef MPE_HIER_UNROLL_TARGETS
+constexpr bool kHierRollF64 = false;
+#else
+constexpr bool kHierRollF64 = true;
+#endif
 
 // Occupancy cap, see mpe_small_kernel.h (L1F2_3Targets f32: 94.2 us uncapped at 5 waves/SIMD, 84.5 us at 3)
 #ifndef MPE_HIER_ATTR
@@ -142,8 +151,7 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
     if constexpr (EREG < E) {
       // the targets, one at a time out of LDS: every agent's sum still grows in ascending b (its agent pairs above, then
       // the targets in order), and the A pair forces of one target are independent instruction streams
-#pragma unroll
-      for (int b = A; b < E; ++b) {
+      auto one_target = [&](int b) {  // the A pair forces of one target
         const T bx = tgt(b - A, 0), by = tgt(b - A, 1);
 #pragma unroll
         for (int a = 0; a < A; ++a) {
@@ -152,6 +160,13 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
           Fx[a] = fx + Fx[a];
           Fy[a] = fy + Fy[a];
         }
+      };
+      if constexpr (sizeof(T) == 8 && kHierRollF64) {
+#pragma nounroll
+        for (int b = A; b < E; ++b) one_target(b);
+      } else {
+#pragma unroll
+        for (int b = A; b < E; ++b) one_target(b);
       }
     }
     const Win<T> wlf(p.lforce + blk0, ld);
@@ -245,8 +260,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         bd[k] = T(0);
         bl[k] = -1;  // empty slot: anything visible goes in front of it
       }
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
+      auto one_target = [&](int l) {
         T dx, dy, d2;
         if constexpr (TLDS) {
           dx = tgt(l, 0) - px[i];
@@ -272,6 +286,13 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
 #else
         n += touching_d2<T>(d2, d.size[A + l] + d.size[i]) ? 1 : 0;
 #endif
+      };
+      if constexpr (TLDS && sizeof(T) == 8 && kHierRollF64) {
+#pragma nounroll
+        for (int l = 0; l < L; ++l) one_target(l);
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l) one_target(l);
       }
       hits[i] = n;
       if (!want_obs) continue;
