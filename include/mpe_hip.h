@@ -103,10 +103,12 @@ extern "C" {
 /* mpe_buffers.flags bits (per call; 0 = default behaviour) */
 #define MPE_FLAG_FORCE_TILE 1u   /* run the generic LDS-tile kernel even for a world that has a register-resident
                                     kernel (tests check both kernels against the same golden vectors; tuning)  */
-#define MPE_FLAG_WIDE 2u         /* simple_tag / simple_spread: always one env per lane, never the small-batch form  */
-#define MPE_FLAG_SPLIT 4u        /* simple_tag / simple_spread: one agent per wavefront (the small-batch form,
-                                    default for B <= MPE_SPLIT_MAX_ENVS) at any batch size.  Both forms produce the
-                                    same bits; the statistics rows group 64 envs instead of 256                      */
+#define MPE_FLAG_WIDE 2u         /* simple_tag / simple_spread / the command-hierarchy worlds (stock shapes): always one env
+                                    per lane, never the small-batch form                                               */
+#define MPE_FLAG_SPLIT 4u        /* the same worlds: one agent per wavefront (the small-batch form, default for
+                                    B <= MPE_SPLIT_MAX_ENVS, for the hierarchy worlds B <= MPE_HIER_SPLIT_MAX_ENVS) at any
+                                    batch size.  Both forms produce the same bits; the statistics rows group 64 envs
+                                    instead of 256                                                                     */
 #define MPE_FLAG_SILENT_COMM_ZERO 8u /* the comm rows of SILENT agents already hold zeros (e.g. the buffer was zeroed when it
                                     was allocated and only the step calls write it): the step leaves them alone instead of
                                     rewriting agent.state.c = zeros(dim_c) (core.py:226-227) every time.  Same state
@@ -123,6 +125,7 @@ extern "C" {
                                     words, hardware log / sin / cos, within ~1e-6 of the f64 normal                  */
 #define MPE_FLAG_ALL 31u
 #define MPE_SPLIT_MAX_ENVS 32768
+#define MPE_HIER_SPLIT_MAX_ENVS 65536
 
 /*
  * World + scenario constants: what Scenario.make_world() sets up (simple_tag.py:7-36,

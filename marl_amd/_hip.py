@@ -33,6 +33,7 @@ FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at a
 FLAG_SILENT_COMM_ZERO = 8   # silent agents' comm rows already hold zeros: the step does not rewrite them
 FLAG_DEVICE_NOISE = 16      # u_noise / c_noise normals the caller does not supply are drawn inside the step kernels
 SPLIT_MAX_ENVS = 32768
+HIER_SPLIT_MAX_ENVS = 65536
 ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA = 0, 1, 2
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)

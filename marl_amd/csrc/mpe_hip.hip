@@ -449,6 +449,7 @@ static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype
   if (sv == SMALL_NONE) return 0;
   if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
   if (small_id_splits(sv, B, flags)) return kSplitEnvs;
+  if (hier_id_splits(sv, B, flags)) return hier_split_envs(sv);
   return kSmallThreads;
 }
 
@@ -457,7 +458,7 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, uint32_t flag
   SmallId sv;
   const int threads = small_launch_threads(h, p.B, (int)sizeof(T), flags, &sv);
   if (threads != 0) {
-    if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, p, s);
+    if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, p, hier_id_splits(sv, p.B, flags), s);
     int noise = 0;  // 1: the caller's normals, 2: drawn in the kernel (MPE_FLAG_DEVICE_NOISE)
     if (DO_STEP && (p.noise != nullptr || (flags & MPE_FLAG_DEVICE_NOISE)))
       for (int a = 0; a < h->n_agents; ++a)

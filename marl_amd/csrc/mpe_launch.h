@@ -64,7 +64,41 @@ int launch_tile_world(const mpe_scenario_desc *h, const KParams<T> &p, hipStream
 template <typename T, bool DO_STEP, bool DO_OBS>
 int launch_stock_id(SmallId sv, const KParams<T> &p, int noise, bool split, hipStream_t s);
 template <typename T, bool DO_STEP, bool DO_OBS>
-int launch_hier_id(SmallId sv, const KParams<T> &p, hipStream_t s);
+int launch_hier_id(SmallId sv, const KParams<T> &p, bool split, hipStream_t s);
 inline bool small_id_is_hier(SmallId sv) { return (sv >= HIER_FIRST && sv <= HIER_LAST) || sv == MOVING_6_4_3 || sv == MOVING_8_4_7; }
+// The command-hierarchy worlds have a one-agent-per-wavefront form too (mpe_hsplit_kernel.h): 64 * kHierSplitEw envs x A
+// wavefronts per workgroup.  MPE_FLAG_SPLIT asks for it, MPE_FLAG_WIDE for the one-env-per-lane form; otherwise it runs
+// for B <= MPE_HIER_SPLIT_MAX_ENVS.  Kernel us per launch, MI355X r3, one env per lane -> one agent per wavefront
+// (tools/hsplit_ab.sh, profiles/r3_hsplit_ab.txt):
+//   S1L2F2_10Targets f64  4 096 envs 39.6 -> 14.8   16 384: 40.6 -> 17.1   65 536: 45.1 -> 37.4   262 144: 124.8 -> 135.0
+//   S1L2F2_10Targets f32  4 096 envs 19.3 -> 10.0   16 384: 20.0 -> 11.0   65 536: 22.7 -> 18.4   262 144:  58.9 ->  65.6
+//   L1F2_3Targets    f64  4 096 envs 13.5 ->  7.9   16 384: 14.3 ->  9.1   65 536: 17.3 -> 14.7   262 144:  47.5 ->  51.8
+//   S1L2F4_Moving    f64  4 096 envs 31.1 -> 11.0   16 384: 32.3 -> 16.7   65 536: 50.3 -> 42.4   262 144: 154.1 -> 163.0
+// and at 1 Mi envs 456 -> 515 us (S1L2F2_10Targets f64): the barriers lock the wavefronts of a workgroup into the same
+// phase (all loading, all in the pair forces, all storing), so loads, arithmetic and stores overlap less than between the
+// free-running wavefronts of the one-env-per-lane form.  Two env groups of 64 per workgroup (1 KiB row segments in f64)
+// were worse still (699 us): fewer, larger phase-locked groups per CU.
+#ifndef MPE_HSPLIT_EW
+#define MPE_HSPLIT_EW 1
+#endif
+constexpr int kHierSplitEw = MPE_HSPLIT_EW;
+constexpr int hier_split_ew(int agents) {  // env groups of 64 per workgroup: at most 1024 lanes
+  return 64 * kHierSplitEw * agents <= 1024 ? kHierSplitEw : (128 * agents <= 1024 ? 2 : 1);
+}
+inline int hier_id_agents(SmallId sv) {
+  switch (sv) {
+    case HIER_2_10_1: return 2;
+    case HIER_3_3_2: case HIER_3_10_2: case HIER_3_10_1: return 3;
+    case HIER_5_3_4: case HIER_5_3_2: case HIER_5_10_2: return 5;
+    case MOVING_6_4_3: return 6;
+    default: return 8;
+  }
+}
+inline int hier_split_envs(SmallId sv) { return 64 * hier_split_ew(hier_id_agents(sv)); }
+inline bool hier_id_splits(SmallId sv, int64_t B, uint32_t flags) {
+  if (!small_id_is_hier(sv)) return false;
+  if (flags & MPE_FLAG_SPLIT) return true;
+  return !(flags & MPE_FLAG_WIDE) && B <= (int64_t)MPE_HIER_SPLIT_MAX_ENVS;
+}
 
 }  // namespace mpe

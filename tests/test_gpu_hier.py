@@ -19,7 +19,7 @@ from oracle import mpe_oracle as O
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_force_tile, stats_rows
+    from tests.gpu_util import HipSim, dev, golden_soa, lib, set_call_flags, set_force_tile, stats_rows
 
 F64_TOL = 1e-9
 BASES = ['L1F2_3Targets_100observe', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
@@ -43,13 +43,14 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + '.npz'))
 
 
-@pytest.fixture(params=[0, 1], ids=['auto_kernel', 'tile_kernel'])
+@pytest.fixture(params=[0, 1, 2], ids=['auto_kernel', 'tile_kernel', 'wide_kernel'])
 def force_tile(request):
-    """The stock shapes run the register kernel (mpe_hier_kernel.h) by default; the hook routes them
-    through the generic LDS-tile kernel too."""
-    set_force_tile(request.param)
+    """The stock shapes run a register kernel by default: at these batch sizes (<= MPE_HIER_SPLIT_MAX_ENVS) the
+    one-agent-per-wavefront form (mpe_hsplit_kernel.h), beyond them the one-env-per-lane form (mpe_hier_kernel.h), which
+    MPE_FLAG_WIDE selects here; the other hook routes them through the generic LDS-tile kernel."""
+    set_call_flags({0: 0, 1: 1, 2: 2}[request.param])
     yield request.param
-    set_force_tile(0)
+    set_call_flags(0)
 
 
 def _maxerr(got, want):
@@ -221,8 +222,8 @@ def test_register_and_tile_kernels_bit_identical(golden_dir, base):
     for dtype in (torch.float64, torch.float32):
         _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 4, 21)
         res = []
-        for ft in (0, 1):
-            set_force_tile(ft)
+        for ft in (2, 1):                                                # MPE_FLAG_WIDE, MPE_FLAG_FORCE_TILE
+            set_call_flags(ft)
             sim = HipSim(spec, B, dtype)
             sim.set_state(pos, vel, lforce=lf0)
             comm = torch.zeros(spec.n_agents, spec.dim_c, B, dtype=dtype, device='cuda')
@@ -234,6 +235,85 @@ def test_register_and_tile_kernels_bit_identical(golden_dir, base):
         set_force_tile(0)
         for x, y in zip(*res):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+# one file per register-kernel shape (mpe_launch.h: HIER_* / MOVING_*) and both reward texts
+SHAPES = ['L1F2_3Targets_100observe', 'L1F4_3Targets_wide', 'L1F1_10Targets_wide', 'L1F2_10Targets_wide',
+          'S1L1F1_10Targets_wide', 'S1L2F2_3Targets_100observe', 'S1L2F2_10Targets_wide',
+          'S1L2F2_10Targets_wide_rewardFixed'] + MOVING
+WIDE, SPLIT = 2, 4
+
+
+def test_default_form_by_batch_size(golden_dir):
+    """B <= MPE_HIER_SPLIT_MAX_ENVS runs one agent per wavefront (statistics rows per 64 envs), larger batches one env
+    per lane (per 256); the two flags override; the tile kernel ignores both."""
+    from marl_amd import _hip
+    n = _hip.HIER_SPLIT_MAX_ENVS
+    for base in ('S1L2F2_10Targets_wide', 'S1L2F4_MovingTarget', 'L1F2_3Targets_100observe'):
+        d = HipSim(_spec_of(golden_dir, base), 8, torch.float32).desc
+        for nbytes in (4, 8):
+            rows = lambda B, f: lib.mpe_stats_rows(d, B, nbytes, f)
+            assert rows(n, 0) == n // 64 and rows(n + 1, 0) == -(-(n + 1) // 256)
+            assert rows(n, WIDE) == n // 256 and rows(4 * n, SPLIT) == 4 * n // 64
+            assert rows(1000, 1) == rows(1000, 1 | WIDE) == rows(1000, 1 | SPLIT)
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('base', SHAPES)
+def test_agent_per_wavefront_form_equals_env_per_lane_form(golden_dir, base, dtype):
+    """mpe_hsplit_kernel.h (one agent per wavefront, MPE_FLAG_SPLIT; the default for the f64 runs of the two largest
+    worlds) against mpe_hier_kernel.h (MPE_FLAG_WIDE): the same bits for state, leader_force, comm, observations,
+    rewards and info from every entry point, on a ragged batch inside a padded allocation; the statistics rows group
+    64 * EW envs instead of 256 (integers equal, reward sums to the last bits)."""
+    spec = _spec_of(golden_dir, base)
+    A = spec.n_agents
+    B, ld = 128 * 11 + 77, 1664
+    _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 4, 31)
+    pos[0, 0, 100:160] = 1.07                                            # bound() penalties
+    pos[A - 1, 1, 140:200] = -1.4
+    acts = [torch.zeros(sum(spec.act_dims), ld, dtype=dtype, device='cuda') for _ in range(4)]
+    rng = np.random.RandomState(9)
+    for a in acts:
+        a[:, :B] = dev(rng.rand(sum(spec.act_dims), B), dtype)
+    W = 2 * A + 2
+    out = {}
+    try:
+        for flags in (WIDE, SPLIT):
+            set_call_flags(flags)
+            fused, parts = HipSim(spec, B, dtype, ld), HipSim(spec, B, dtype, ld)
+            rows = stats_rows(fused.desc, B, fused.pos.element_size())
+            assert rows == -(-B // (256 if flags == WIDE else 64))
+            stats = torch.zeros(rows, W, dtype=torch.float64, device='cuda')
+            comm = torch.full((A, spec.dim_c, ld), 7.0, dtype=dtype, device='cuda')
+            for s in (fused, parts):
+                s.set_state(pos, vel, lforce=lf0)
+            fused.observe()
+            first = [t.copy() for t in fused.host()]
+            for a in acts:
+                fused.env_step(a, stats=stats, comm=comm)
+                parts.world_step(a)
+                parts.observe()
+            names = ('pos', 'vel', 'obs', 'rew', 'info', 'lforce')
+            for nm, x, y in zip(names, fused.host() + (fused.lforce.cpu().numpy(),),
+                                parts.host() + (parts.lforce.cpu().numpy(),)):
+                bad = ~((x == y) | (np.isnan(x) & np.isnan(y)))
+                assert not bad.any(), (flags, nm, np.unique(np.nonzero(bad)[0])[:20], np.nonzero(bad)[-1][:10])
+            assert (comm[:, :, B:] == 7).all()
+            for t in (fused.obs, fused.rew, fused.info):
+                assert torch.isnan(t[..., B:]).all()                      # padding never written
+            assert (fused.pos[..., B:] == 0).all() and (fused.lforce[..., B:] == 0).all()
+            red = torch.empty(W, dtype=torch.float64, device='cuda')
+            assert lib.mpe_stats_reduce(stats.data_ptr(), rows, W, red.data_ptr(), fused.stream) == 0
+            out[flags] = (first + list(fused.host()) + [fused.lforce.cpu().numpy(), comm.cpu().numpy()],
+                          red.cpu().numpy())
+    finally:
+        set_call_flags(0)
+    for x, y in zip(out[WIDE][0], out[SPLIT][0]):
+        assert np.array_equal(x, y, equal_nan=True)
+    sw, ss = out[WIDE][1], out[SPLIT][1]
+    assert np.array_equal(sw[A:], ss[A:])                                # contact counters, env count: integers
+    np.testing.assert_allclose(ss[:A], sw[:A], rtol=1e-12)
+    assert sw[2 * A + 1] == 4 * B and sw[A:2 * A + 1].sum() > 0           # target hits / prey contacts happened
 
 
 @pytest.mark.parametrize('base', ['S1L2F2_10Targets_wide', 'S1L2F4_MovingTarget'])
