@@ -676,6 +676,42 @@ __device__ __forceinline__ T tag_bound_sel(T x) {
   return x < T(0.9) ? T(0) : (x < T(1.0) ? mid : hi);
 }
 
+// The NT nearest visible targets of one observer as a list sorted by (d2, index), kept while the targets stream by in
+// index order (L1F2_3Targets_100observe.py:242-245: a stable sort of the visible targets by squared distance).  Slots
+// start at (+inf, -1); an invisible target enters as +inf and stops in front of nothing.  One candidate bubbles
+// through the list: the strict comparison leaves an equal, earlier-index entry in front, like the stable sort; the
+// distances move with v_min / v_max, only the indices need selects (13 vector instructions for NT = 3, no branches:
+// the select form of the same insertion compiled to three exec-mask regions per target).
+template <typename T> __device__ __forceinline__ T t_min(T a, T b);
+template <> __device__ __forceinline__ float t_min<float>(float a, float b) { return __builtin_fminf(a, b); }
+template <> __device__ __forceinline__ double t_min<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <typename T> __device__ __forceinline__ T t_max(T a, T b);
+template <> __device__ __forceinline__ float t_max<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <> __device__ __forceinline__ double t_max<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <typename T, int NT>
+__device__ __forceinline__ void nearest_init(T (&bd)[NT], int (&bl)[NT]) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    bd[k] = T(INFINITY);
+    bl[k] = -1;  // empty slot
+  }
+}
+template <typename T, int NT>
+__device__ __forceinline__ void nearest_insert(T (&bd)[NT], int (&bl)[NT], T d2, bool seen, int l) {
+  T x = seen ? d2 : T(INFINITY);  // (a NaN d2 is not seen: NaN < r2 is false)
+  int xi = l;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const bool front = x < bd[k];
+    const T lo = t_min<T>(bd[k], x), hi = t_max<T>(bd[k], x);
+    const int li = front ? xi : bl[k], hi_i = front ? bl[k] : xi;
+    bd[k] = lo;
+    bl[k] = li;
+    x = hi;
+    xi = hi_i;
+  }
+}
+
 // Sum over the `width` consecutive lanes (width = 32 or 64) that contain this lane.
 __device__ __forceinline__ double group_sum(double v, int width) {
 #pragma unroll

@@ -255,27 +255,14 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       const T r2 = d.obs_r2[i];
       T bd[NT];
       int bl[NT];
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        bd[k] = T(0);
-        bl[k] = -1;  // empty slot: anything visible goes in front of it
-      }
+      nearest_init<T, NT>(bd, bl);
       auto one_target = [&](int l) {
         T dx, dy, d2;
         if constexpr (TLDS) {
           dx = tgt(l, 0) - px[i];
           dy = tgt(l, 1) - py[i];
           d2 = dx * dx + dy * dy;
-          const bool seen = d2 < r2;
-          bool in[NT];  // goes in front of slot k
-#pragma unroll
-          for (int k = 0; k < NT; ++k) in[k] = seen && (bl[k] < 0 || d2 < bd[k]);
-#pragma unroll
-          for (int k = NT - 1; k >= 0; --k) {
-            const bool shift = k > 0 && in[k - 1];  // the new one lands further in front: slot k takes slot k - 1
-            bd[k] = shift ? bd[k - 1] : (in[k] ? d2 : bd[k]);
-            bl[k] = shift ? bl[k - 1] : (in[k] ? l : bl[k]);
-          }
+          nearest_insert<T, NT>(bd, bl, d2, d2 < r2, l);
         } else {
           dx = tdx[l] = px[A + l] - px[i];
           dy = tdy[l] = py[A + l] - py[i];

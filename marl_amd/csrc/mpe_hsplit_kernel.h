@@ -196,26 +196,13 @@ __global__ __launch_bounds__(64 * EW * A) MPE_HSPLIT_ATTR void hier_split_kernel
       // strict comparisons: a tie leaves the earlier index in front, like the reference's stable sort (:242-245)
       T bd[NT];
       int bl[NT];
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        bd[k] = T(0);
-        bl[k] = -1;  // empty slot: anything visible goes in front of it
-      }
+      nearest_init<T, NT>(bd, bl);
       int n = 0;
 #pragma nounroll
       for (int l = 0; l < L; ++l) {
         const T dx = sP[2 * (A + l)][col] - mpx, dy = sP[2 * (A + l) + 1][col] - mpy;
         const T d2 = dx * dx + dy * dy;
-        const bool seen = d2 < r2;
-        bool in[NT];  // goes in front of slot k
-#pragma unroll
-        for (int k = 0; k < NT; ++k) in[k] = seen && (bl[k] < 0 || d2 < bd[k]);
-#pragma unroll
-        for (int k = NT - 1; k >= 0; --k) {
-          const bool shift = k > 0 && in[k > 0 ? k - 1 : 0];  // the new one lands further in front
-          bd[k] = shift ? bd[k > 0 ? k - 1 : 0] : (in[k] ? d2 : bd[k]);
-          bl[k] = shift ? bl[k > 0 ? k - 1 : 0] : (in[k] ? l : bl[k]);
-        }
+        nearest_insert<T, NT>(bd, bl, d2, d2 < r2, l);
         n += touching_d2<T>(d2, d.size[A + l] + d.size[me]) ? 1 : 0;
       }
       sH[me][col] = n;
