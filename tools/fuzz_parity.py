@@ -2,7 +2,7 @@
 and random per-entity constants (sizes, masses, accel None or a value, max_speed None or a value, collide flags in
 irregular patterns, u_noise on some agents, damping / dt / contact constants), dense starts so that contacts happen.
 f64, every output of 3 steps within 1e-9 (NaN patterns equal).  Run on the GPU box from the repo root:
-    python tools/fuzz_parity.py [n_worlds] [seed]
+    python tools/fuzz_parity.py [n_worlds] [seed] [stock]      (stock: only the shapes that have register kernels)
 Prints one line per mismatch or refusal and a summary; exit status 1 if anything differs."""
 import dataclasses
 import os
@@ -53,10 +53,55 @@ def random_hier(rng):
         reward_variant=int(rng.randint(0, 2)), n_target_obs=3)
 
 
-def random_spec(rng):
-    kind = rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier', 'wcomm', 'big'])
+_STOCK = ['h_L1F2_3Targets_100observe', 'h_L1F4_3Targets_wide', 'h_L1F1_10Targets_wide', 'h_L1F2_10Targets_wide',
+          'h_S1L1F1_10Targets_wide', 'h_S1L2F2_3Targets_100observe', 'h_S1L2F2_10Targets_wide', 'm_L1F4_MovingTarget',
+          'm_S1L2F4_MovingTarget']
+_stock_cache = {}
+
+
+def random_stock_hier(rng):
+    """One of the nine shapes that have register kernels (mpe_launch.h: HIER_* / MOVING_*), with everything those
+    kernels read at run time drawn at random: sizes, masses, accel, speed limits, observation radii, who commands whom
+    (the followers' and leaders' forced_id, the leaders' force_id), the reward text, the world constants.  What the
+    shape fixes stays: counts, who speaks, dim_c, every entity collides, every agent has a max_speed."""
+    name = _STOCK[int(rng.randint(len(_STOCK)))]
+    if name not in _stock_cache:
+        g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', name + '.npz'))
+        _stock_cache[name] = O.hier_spec_from_golden(g)
+    spec = _stock_cache[name]
+    A, E = spec.n_agents, spec.n_entities
+    pick = lambda p: rng.rand() < p
+    force_id, forced_id = list(spec.force_id), list(spec.forced_id)
+    lead = [not spec.silent[i] for i in range(A)]
+    sup = list(spec.advsuperleader)
+    if pick(0.7):
+        sup_id = [force_id[i] for i in range(A) if sup[i]]          # never shared with a plain leader (both sides refuse)
+        pool = [k for k in (1, 2, 3, 4) if k not in sup_id][:2]
+        for i in range(A):
+            if lead[i] and not sup[i]:
+                force_id[i] = int(rng.choice(pool))
+                forced_id[i] = sup_id[0] if (sup_id and pick(0.6)) else -1
+            elif not lead[i]:
+                forced_id[i] = int(rng.choice([-1] + pool))
+    rep = dict(force_id=force_id, forced_id=forced_id,
+               size=[float(rng.uniform(0.03, 0.15)) for _ in range(E)],
+               mass=[float(rng.choice([1.0, 1.0, 0.5, 2.5])) for _ in range(E)],
+               accel=[None if pick(0.15) else float(rng.uniform(2, 5)) for _ in range(A)],
+               max_speed=[float(rng.uniform(0.3, 1.5)) for _ in range(A)],
+               obs_r=[float(rng.uniform(0.1, 1.2)) for _ in range(A)], reward_variant=int(rng.randint(0, 2)))
+    if pick(0.4):
+        rep.update(damping=float(rng.uniform(0.0, 0.5)), dt=float(rng.uniform(0.05, 0.2)),
+                   contact_force=float(rng.uniform(20, 200)), contact_margin=float(10 ** rng.uniform(-3, -2)))
+    return 'stock_hier', dataclasses.replace(spec, **rep)
+
+
+def random_spec(rng, stock_only=False):
+    kind = 'stock_hier' if stock_only else rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier',
+                                                       'wcomm', 'big', 'stock_hier'])
     if kind == 'hier':
         return random_hier(rng)
+    if kind == 'stock_hier':
+        return random_stock_hier(rng)
     if kind == 'tag':
         spec = O.simple_tag_spec(int(rng.randint(1, 7)), int(rng.randint(1, 5)), int(rng.randint(0, 6)))
     elif kind == 'spread':
@@ -101,7 +146,7 @@ def random_spec(rng):
     return kind, dataclasses.replace(spec, **rep)
 
 
-def run(n_worlds, seed, perturb=0.0):
+def run(n_worlds, seed, perturb=0.0, stock_only=False):
     """-> (mismatching runs, worlds refused by mpe_desc_check, worlds per kind).  perturb != 0: the oracle steps a world
     whose damping differs by that much (negative control: the comparison must notice)."""
     rng = np.random.RandomState(seed)
@@ -109,18 +154,21 @@ def run(n_worlds, seed, perturb=0.0):
     bad = refused = 0
     kernels = {}
     for w in range(n_worlds):
-        kind, spec = random_spec(rng)
+        kind, spec = random_spec(rng, stock_only)
         d = desc_from_spec_or_none(spec)
         if d is None:
             refused += 1
             continue
         A, E = spec.n_agents, spec.n_entities
+        if kind == 'stock_hier':  # the random constants must not push the world off its register kernels
+            rows = [_hip.lib.mpe_stats_rows(d, B, 8, f) for f in (0, 2)]
+            assert rows == [-(-B // 64), -(-B // 256)], (rows, spec)
         pos = rng.uniform(-0.45, 0.45, (E, 2, B))
         vel = rng.uniform(-0.8, 0.8, (A, 2, B))
         lm_moves = any(spec.movable[A:])
         lvel0 = rng.uniform(-0.8, 0.8, (E - A, 2, B)) * np.asarray(spec.movable[A:], float)[:, None, None] if lm_moves else None
         goal = rng.randint(0, max(spec.n_landmarks, 1), B)
-        hier = spec.kind == O.HIER_PURSUIT
+        hier = spec.kind in (O.HIER_PURSUIT, O.HIER_MOVING)
         ragged = hier or spec.kind == O.WORLD_COMM
         lf0 = rng.uniform(-1, 1, (A, 2, B)) if hier and spec.has_leader_force else None
         acts = [rng.rand(sum(spec.act_dims), B) if ragged else rng.dirichlet(np.ones(5), (A, B)).transpose(0, 2, 1)
@@ -128,7 +176,9 @@ def run(n_worlds, seed, perturb=0.0):
         noises = [rng.randn(A, 2, B) for _ in range(T)]
         has_noise = any(spec.u_noise)
         bo = O.BatchedOracle(dataclasses.replace(spec, damping=spec.damping + perturb) if perturb else spec)
-        for flags in (0, 1):
+        # 0: the kernel the library picks (a register kernel for the stock shapes: one agent per wavefront at this batch
+        # size), 1: MPE_FLAG_FORCE_TILE, 2: MPE_FLAG_WIDE (one env per lane; the stock hierarchy shapes only)
+        for flags in ((0, 1, 2) if kind == 'stock_hier' else (0, 1)):
             set_call_flags(flags)
             try:
                 sim = HipSim(spec, B, torch.float64)
@@ -199,7 +249,7 @@ def run(n_worlds, seed, perturb=0.0):
 def main():
     n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, refused, kinds = run(n_worlds, seed)
+    bad, refused, kinds = run(n_worlds, seed, stock_only=len(sys.argv) > 3 and sys.argv[3] == 'stock')
     print('worlds %d (refused by mpe_desc_check: %d), by kind %s, mismatching (world, kernel) runs: %d'
           % (n_worlds, refused, kinds, bad))
     sys.exit(1 if bad else 0)
