@@ -95,7 +95,30 @@ def random_stock_hier(rng):
     return 'stock_hier', dataclasses.replace(spec, **rep)
 
 
+def random_stock_small(rng):
+    """A stock scenario in the shape its register kernel is built for (mpe_small_kernel.h / mpe_comm_kernel.h /
+    mpe_wcomm_kernel.h) with the constants those kernels read at run time drawn at random: sizes, masses, accel, the
+    values of the speed limits (who has one is part of the shape), u_noise, the world constants."""
+    mk = [O.simple_tag_spec, O.simple_spread_spec, O.simple_spec, O.simple_adversary_spec, O.simple_push_spec,
+          O.speaker_listener_spec, O.simple_reference_spec, O.simple_crypto_spec, O.simple_world_comm_spec]
+    spec = mk[int(rng.randint(len(mk)))]()
+    A, E = spec.n_agents, spec.n_entities
+    pick = lambda p: rng.rand() < p
+    rep = dict(size=[float(rng.uniform(0.02, 0.25)) for _ in range(E)],
+               mass=[float(rng.choice([1.0, 1.0, 0.5, 2.5])) for _ in range(E)],
+               accel=[None if pick(0.2) else float(rng.uniform(1, 6)) for _ in range(A)],
+               max_speed=[None if m is None else float(rng.uniform(0.3, 1.5)) for m in spec.max_speed])
+    if spec.kind in (O.SIMPLE_TAG, O.SIMPLE_SPREAD) and pick(0.4):
+        rep['u_noise'] = [None if pick(0.4) else float(rng.uniform(0.05, 0.5)) for _ in range(A)]
+    if pick(0.4):
+        rep.update(damping=float(rng.uniform(0.0, 0.5)), dt=float(rng.uniform(0.05, 0.2)),
+                   contact_force=float(rng.uniform(20, 200)), contact_margin=float(10 ** rng.uniform(-3, -2)))
+    return 'stock_small', dataclasses.replace(spec, **rep)
+
+
 def random_spec(rng, stock_only=False):
+    if stock_only and rng.rand() < 0.5:
+        return random_stock_small(rng)
     kind = 'stock_hier' if stock_only else rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier',
                                                        'wcomm', 'big', 'stock_hier'])
     if kind == 'hier':
@@ -163,13 +186,21 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False):
         if kind == 'stock_hier':  # the random constants must not push the world off its register kernels
             rows = [_hip.lib.mpe_stats_rows(d, B, 8, f) for f in (0, 2)]
             assert rows == [-(-B // 64), -(-B // 256)], (rows, spec)
+        if kind == 'stock_small':
+            splits = spec.kind in (O.SIMPLE_TAG, O.SIMPLE_SPREAD)
+            on_tile = spec.kind == O.SIMPLE_PUSH     # 10 agents in f64: more than 256 VGPRs, the tile kernel takes it
+            rows = [_hip.lib.mpe_stats_rows(d, B, 8, f) for f in (0, 2)]
+            assert on_tile or rows == [-(-B // (64 if splits else 256)), -(-B // 256)], (rows, spec)
         pos = rng.uniform(-0.45, 0.45, (E, 2, B))
         vel = rng.uniform(-0.8, 0.8, (A, 2, B))
         lm_moves = any(spec.movable[A:])
         lvel0 = rng.uniform(-0.8, 0.8, (E - A, 2, B)) * np.asarray(spec.movable[A:], float)[:, None, None] if lm_moves else None
-        goal = rng.randint(0, max(spec.n_landmarks, 1), B)
+        gr = spec.goal_rows                  # per-env goal landmark(s): one row, or one per agent (simple_reference)
+        goal = (rng.randint(0, max(spec.n_landmarks, 1), B) if spec.kind in O.GOAL_KINDS or gr == 0
+                else rng.randint(0, spec.n_landmarks, (gr, B)))
+        goal_arg = goal if gr else None
         hier = spec.kind in (O.HIER_PURSUIT, O.HIER_MOVING)
-        ragged = hier or spec.kind == O.WORLD_COMM
+        ragged = hier or not all(spec.silent)
         lf0 = rng.uniform(-1, 1, (A, 2, B)) if hier and spec.has_leader_force else None
         acts = [rng.rand(sum(spec.act_dims), B) if ragged else rng.dirichlet(np.ones(5), (A, B)).transpose(0, 2, 1)
                 for _ in range(T)]
@@ -177,8 +208,8 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False):
         has_noise = any(spec.u_noise)
         bo = O.BatchedOracle(dataclasses.replace(spec, damping=spec.damping + perturb) if perturb else spec)
         # 0: the kernel the library picks (a register kernel for the stock shapes: one agent per wavefront at this batch
-        # size), 1: MPE_FLAG_FORCE_TILE, 2: MPE_FLAG_WIDE (one env per lane; the stock hierarchy shapes only)
-        for flags in ((0, 1, 2) if kind == 'stock_hier' else (0, 1)):
+        # size), 1: MPE_FLAG_FORCE_TILE, 2: MPE_FLAG_WIDE (one env per lane; the stock shapes only)
+        for flags in ((0, 1, 2) if kind in ('stock_hier', 'stock_small') else (0, 1)):
             set_call_flags(flags)
             try:
                 sim = HipSim(spec, B, torch.float64)
@@ -189,7 +220,7 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False):
                 for t in range(T):
                     sim.env_step(dev(acts[t], torch.float64), dev(noises[t], torch.float64) if has_noise else None)
                     res = bo.env_step(p, v, acts[t], noises[t] if has_noise else None,
-                                      goal=goal if spec.kind in O.GOAL_KINDS else None, lvel=lv)
+                                      goal=goal_arg, lvel=lv)
                     p, v, obs, rew, info = res[:5]
                     lv = res[5] if lm_moves else None
                     got = sim.host() + ((sim.lvel.cpu().numpy(),) if lm_moves else ())
@@ -214,7 +245,7 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False):
         # f32 (its own arithmetic and, in the tile kernel, its own pair-loop shape): ONE step from the same state; the
         # continuous outputs within 1e-4 of the f64 oracle (observations only where they carry no visibility masks)
         p1, v1, obs1 = bo.env_step(pos, vel, acts[0], noises[0] if has_noise else None,
-                                   goal=goal if spec.kind in O.GOAL_KINDS else None, lvel=lvel0)[:3]
+                                   goal=goal_arg, lvel=lvel0)[:3]
         if not perturb and np.isfinite(p1).all():
             sim = HipSim(spec, B, torch.float32)
             sim.set_state(pos, vel, goal, lf0)
@@ -232,7 +263,7 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False):
             # ... and no worse than a few times what the same operations in numpy float32 lose on this world (the speed
             # clamp turns a cancellation error of the force into an error of the direction, whatever |v| is)
             p32, v32 = O.BatchedOracle(spec, np.float32).env_step(
-                pos, vel, acts[0], noises[0] if has_noise else None, goal=goal if spec.kind in O.GOAL_KINDS else None,
+                pos, vel, acts[0], noises[0] if has_noise else None, goal=goal_arg,
                 lvel=lvel0)[:2]
             slack = 8.0 * max(float(np.nanmax(np.abs(np.asarray(v32, np.float64) - v1))),
                               float(np.nanmax(np.abs(np.asarray(p32, np.float64) - p1))))
