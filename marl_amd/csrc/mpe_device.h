@@ -5,6 +5,7 @@
 // that the device exp/log1p allow.  The library is compiled with -ffp-contract=off: no FMA is
 // formed unless written explicitly.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -49,6 +50,14 @@ struct DevDesc {
   int8_t forced_id[MPE_MAX_AGENTS];
   T obs_r2[MPE_MAX_AGENTS];  // obs_r * obs_r, evaluated in T (L1F2_3Targets_100observe.py:206)
 };
+
+// desc_i8 / desc_u8 (below) read the byte arrays as aligned 32-bit words
+static_assert(offsetof(DevDesc<float>, adv_list) % 4 == 0 && offsetof(DevDesc<float>, good_list) % 4 == 0 &&
+                  offsetof(DevDesc<float>, force_id) % 4 == 0 && offsetof(DevDesc<float>, forced_id) % 4 == 0 &&
+                  offsetof(DevDesc<double>, adv_list) % 4 == 0 && offsetof(DevDesc<double>, good_list) % 4 == 0 &&
+                  offsetof(DevDesc<double>, force_id) % 4 == 0 && offsetof(DevDesc<double>, forced_id) % 4 == 0 &&
+                  MPE_MAX_AGENTS % 4 == 0,
+              "byte arrays of the descriptor start on word boundaries");
 
 // entity sizes alone (kernels that need nothing else of the descriptor)
 template <typename T>
@@ -173,6 +182,21 @@ struct Win {
 };
 
 __device__ __forceinline__ bool bit(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+
+// An entry of one of the descriptor's BYTE arrays (force_id, forced_id, adv_list, good_list) at a run-time index: read
+// as the aligned 32-bit word that holds it.  With a plain byte access the compiler keeps `kernarg + i` as a scalar base
+// and reuses it, plus 3 i, for the 4-byte arrays indexed by the same i (s_load_dword s, s[kernarg + i], s[3 i] offset:...),
+// but the scalar memory unit drops the two low bits of the BASE before it adds the offsets (tools/smem_align_probe.hip,
+// MI355X: base t + 1, offset 3 reads entry 0, not entry 1): agent 1 then got agent 0's 4-byte constants.  Seen in the f32
+// observe-only instantiation of mpe_hsplit_kernel.h; every kernel reads these arrays through here since.
+__device__ __forceinline__ int desc_i8(const int8_t *arr, int i) {
+  const uint32_t w = reinterpret_cast<const uint32_t *>(arr)[i >> 2];
+  return (int)(int8_t)(w >> (8 * (i & 3)));
+}
+__device__ __forceinline__ int desc_u8(const uint8_t *arr, int i) {
+  const uint32_t w = reinterpret_cast<const uint32_t *>(arr)[i >> 2];
+  return (int)((w >> (8 * (i & 3))) & 0xFFu);
+}
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -425,10 +449,10 @@ __device__ __forceinline__ void leader_force(const KParams<T> &p, int a, int64_t
   const DevDesc<T> &d = p.d;
   lfx = T(0);
   lfy = T(0);
-  const int want = d.forced_id[a];
+  const int want = desc_i8(d.forced_id, a);
   if (want < 0) return;
   for (int l = 0; l < d.A; ++l) {
-    if (d.force_id[l] != want) continue;
+    if (desc_i8(d.force_id, l) != want) continue;
     const bool mute = bit(d.silent, l);  // action.c stays zeros(dim_c) (core.py:32-36)
     const T *c = p.act + (int64_t)d.cact_row0[l] * p.ld + col;
     if (bit(d.advsuper, l)) {

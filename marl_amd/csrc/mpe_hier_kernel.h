@@ -96,11 +96,11 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-      const int want = d.forced_id[a];
+      const int want = desc_i8(d.forced_id, a);
       if (want < 0) continue;
 #pragma unroll
       for (int l = NF; l < LE; ++l) {  // silent agents command nobody: their c is zero (argmax 0)
-        if (d.force_id[l] != want) continue;
+        if (desc_i8(d.force_id, l) != want) continue;
         if (bit(d.advsuper, l)) {  // observed only (core.py:162-163)
           lfx[a] = c[l - NF][0];
           lfy[a] = c[l - NF][1];
@@ -194,7 +194,7 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
     const Win<T> wlf0(p.lforce + blk0, ld);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-      if (d.forced_id[a] < 0) continue;  // only commanded agents observe it
+      if (desc_i8(d.forced_id, a) < 0) continue;  // only commanded agents observe it
       lfx[a] = wlf0.ld_state(2 * a, lo);
       lfy[a] = wlf0.ld_state(2 * a + 1, lo);
     }
@@ -289,13 +289,13 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
       wobs.st_stream(r++, lo, vy[i]);
       wobs.st_stream(r++, lo, px[i]);
       wobs.st_stream(r++, lo, py[i]);
-      const int fi = d.force_id[i], fdi = d.forced_id[i];
+      const int fi = desc_i8(d.force_id, i), fdi = desc_i8(d.forced_id, i);
       bool vis[A];
 #pragma unroll
       for (int j = 0; j < A; ++j) {
         if (j == i) continue;
         const T dx = px[j] - px[i], dy = py[j] - py[i];
-        const bool linked = (fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]);
+        const bool linked = (fi >= 0 && fi == desc_i8(d.forced_id, j)) || (fdi >= 0 && fdi == desc_i8(d.force_id, j));
         vis[j] = linked || (dx * dx + dy * dy < r2);
         wobs.st_stream(r++, lo, vis[j] ? dx : T(0));
         wobs.st_stream(r++, lo, vis[j] ? dy : T(0));
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
 #pragma unroll
       for (int i = 0; i < A; ++i) {
         const bool lead = bit(d.advleader, i), super = bit(d.advsuper, i);
-        const int fi = d.force_id[i];
+        const int fi = desc_i8(d.force_id, i);
         const bool own = d.reward_variant == 0 ? !lead : (!super && !lead);
         int n = 0;
         T unit = T(10);
@@ -367,10 +367,10 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
         } else if (d.reward_variant == 1 && super) {
           unit = T(1);
 #pragma unroll
-          for (int o = 0; o < A; ++o) n += (d.forced_id[o] == fi && T(0) < d.obs_r2[o]) ? L : 0;
+          for (int o = 0; o < A; ++o) n += (desc_i8(d.forced_id, o) == fi && T(0) < d.obs_r2[o]) ? L : 0;
         } else {
 #pragma unroll
-          for (int o = 0; o < A; ++o) n += d.forced_id[o] == fi ? hits[o] : 0;
+          for (int o = 0; o < A; ++o) n += desc_i8(d.forced_id, o) == fi ? hits[o] : 0;
         }
         T r_i = unit * T(n);
         r_i = r_i - tag_bound_sel<T>(t_abs<T>(px[i]));
@@ -489,14 +489,14 @@ __global__ __launch_bounds__(THREADS) MPE_MOVING_ATTR void moving_kernel(const K
         wobs.st_stream(r++, lo, vy[i]);
         wobs.st_stream(r++, lo, px[i]);
         wobs.st_stream(r++, lo, py[i]);
-        const int fi = d.force_id[i], fdi = d.forced_id[i];
+        const int fi = desc_i8(d.force_id, i), fdi = desc_i8(d.forced_id, i);
         bool vis[A];
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           if (j == i) continue;
           const T dx = px[j] - px[i], dy = py[j] - py[i];
           const bool linked = d.reward_variant == 0 &&
-                              ((fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]));
+                              ((fi >= 0 && fi == desc_i8(d.forced_id, j)) || (fdi >= 0 && fdi == desc_i8(d.force_id, j)));
 #ifndef MPE_MOVING_SQRT_VIS
           vis[j] = i == G || linked || ((near >> (8 * i + j)) & 1);
 #else

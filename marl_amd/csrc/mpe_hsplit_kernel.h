@@ -24,15 +24,6 @@
 
 namespace mpe {
 
-// force_id / forced_id of agent i, i a run-time scalar.  Read as the aligned 32-bit word that holds the byte: with a plain
-// byte access the compiler keeps `kernarg + i` as a scalar base and reuses it, plus 3 i, for the 4-byte descriptor arrays
-// indexed by the same i (s_load_dword s, s[base + i], s[3 i] offset:...), and the scalar load aligns that odd base down
-// before it adds the offset: agent 1 then read entry 0 (seen on the f32 observe-only instantiation, MI355X).
-__device__ __forceinline__ int desc_i8(const int8_t *arr, int i) {
-  const uint32_t w = reinterpret_cast<const uint32_t *>(arr)[i >> 2];
-  return (int)(int8_t)(w >> (8 * (i & 3)));
-}
-
 #ifndef MPE_HSPLIT_ATTR
 #define MPE_HSPLIT_ATTR
 #endif

@@ -176,8 +176,8 @@ __device__ __forceinline__ void obs_rows_vec_impl(const KParams<T> &p, const T *
         const int ga = b0 >> 1, gb = ga + 1;
         // LGLOB: the velocity rows in LDS are indexed by position in the good list, not by agent
         const int sa = ga + (ga >= rank ? 1 : 0), sb = gb + (gb >= rank ? 1 : 0);
-        const int ja = LGLOB ? sa : d.good_list[sa];
-        const int jb = 2 * gb < nrows ? (LGLOB ? sb : d.good_list[sb]) : ja;
+        const int ja = LGLOB ? sa : desc_u8(d.good_list, sa);
+        const int jb = 2 * gb < nrows ? (LGLOB ? sb : desc_u8(d.good_list, sb)) : ja;
         const bool ok = b0 + r < nrows;
         const VT v = *reinterpret_cast<const VT *>(sVel + (2 * (r >> 1 ? jb : ja) + (r & 1)) * TILE + lcol);
         if (ok) st_stream_vec<T>(o + (int64_t)b0 * ld, v, nvalid, FULL);
@@ -627,14 +627,14 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
             o += 4 * ld;
             const bool i_adv = bit(d.adversary, i);
             const T rad = d.obs_r[i];
-            const int fi = d.force_id[i], fdi = d.forced_id[i];
+            const int fi = desc_i8(d.force_id, i), fdi = desc_i8(d.forced_id, i);
             uint64_t vis = 0;
             for (int j = 0; j < A; ++j) {
               if (j == i) continue;
               const T pjx = sPos[(2 * j) * TILE + lane], pjy = sPos[(2 * j + 1) * TILE + lane];
               const T dx = pjx - pix, dy = pjy - piy;
               const bool linked = d.reward_variant == 0 &&
-                                  ((fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]));
+                                  ((fi >= 0 && fi == desc_i8(d.forced_id, j)) || (fdi >= 0 && fdi == desc_i8(d.force_id, j)));
               const bool v = !i_adv || linked || t_sqrt<T>(dx * dx + dy * dy) < rad;
               vis |= (uint64_t)v << j;
               // the prey sees everybody, in absolute coordinates (:249-251)
@@ -663,12 +663,12 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
             st_stream(o + 3 * ld, piy);
             o += 4 * ld;
             const T r2 = d.obs_r2[i];
-            const int fi = d.force_id[i], fdi = d.forced_id[i];
+            const int fi = desc_i8(d.force_id, i), fdi = desc_i8(d.forced_id, i);
             uint64_t vis = 0;  // others inside the radius or on the same command link (:209-216)
             for (int j = 0; j < A; ++j) {
               if (j == i) continue;
               const T dx = sPos[(2 * j) * TILE + lane] - pix, dy = sPos[(2 * j + 1) * TILE + lane] - piy;
-              const bool linked = (fi >= 0 && fi == d.forced_id[j]) || (fdi >= 0 && fdi == d.force_id[j]);
+              const bool linked = (fi >= 0 && fi == desc_i8(d.forced_id, j)) || (fdi >= 0 && fdi == desc_i8(d.force_id, j));
               const bool v = linked || (dx * dx + dy * dy < r2);
               vis |= (uint64_t)v << j;
               st_stream(o, v ? dx : T(0));
@@ -785,12 +785,12 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           __syncthreads();
           int part = 0;  // this chunk's share of sum_{g,a} hit
           for (int gi = chunk; gi < d.n_good; gi += NCH) {
-            const int g = d.good_list[gi];
+            const int g = desc_u8(d.good_list, gi);
             const T pgx = sPos[(2 * g) * TILE + lane], pgy = sPos[(2 * g + 1) * TILE + lane];
             const T sg = d.size[g];
             int n = 0;
             for (int ai = 0; ai < d.n_adv; ++ai) {
-              const int a = d.adv_list[ai];
+              const int a = desc_u8(d.adv_list, ai);
               if (touching<T>(pgx - sPos[(2 * a) * TILE + lane], pgy - sPos[(2 * a + 1) * TILE + lane],
                               sg + d.size[a])) {
                 ++n;
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           // adversary_reward (simple_tag.py:115-129): same value for every adversary;
           // benchmark_data (simple_tag.py:57-64): goods touching this adversary
           for (int ai = chunk; ai < d.n_adv; ai += NCH) {
-            const int i = d.adv_list[ai];
+            const int i = desc_u8(d.adv_list, ai);
             const int n = LGLOB ? (sCnt[(ai / PK) * TILE + lane] >> (8 * (ai % PK))) & 0xFF : sCnt[ai * TILE + lane];
             const T r_i = bit(d.collide, i) ? T(10) * T(total) : T(0);
             if (want_rew && active) st_stream(p.rew + (int64_t)i * ld + env, r_i);
@@ -851,18 +851,18 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
             if (bit(d.adversary, i)) {
               T m = T(0);
               for (int gi = 0; gi < d.n_good; ++gi) {
-                const T dg = dist(d.good_list[gi], i);
+                const T dg = dist(desc_u8(d.good_list, gi), i);
                 m = (gi == 0 || dg < m) ? dg : m;
               }
               r_i = r_i - T(0.1) * m;
               if (bit(d.collide, i))
                 for (int gi = 0; gi < d.n_good; ++gi)
                   for (int ai = 0; ai < d.n_adv; ++ai)
-                    r_i = hit(d.good_list[gi], d.adv_list[ai]) ? r_i + T(5) : r_i;
-              for (int gi = 0; gi < d.n_good; ++gi) c_i += hit(d.good_list[gi], i) ? 1 : 0;
+                    r_i = hit(desc_u8(d.good_list, gi), desc_u8(d.adv_list, ai)) ? r_i + T(5) : r_i;
+              for (int gi = 0; gi < d.n_good; ++gi) c_i += hit(desc_u8(d.good_list, gi), i) ? 1 : 0;
             } else {
               if (bit(d.collide, i))
-                for (int ai = 0; ai < d.n_adv; ++ai) r_i = hit(d.adv_list[ai], i) ? r_i - T(5) : r_i;
+                for (int ai = 0; ai < d.n_adv; ++ai) r_i = hit(desc_u8(d.adv_list, ai), i) ? r_i - T(5) : r_i;
               r_i = r_i - T(2) * tag_bound<T>(t_abs<T>(sPos[(2 * i) * TILE + lane]));
               r_i = r_i - T(2) * tag_bound<T>(t_abs<T>(sPos[(2 * i + 1) * TILE + lane]));
               T m = T(0);
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           if (want_stats && chunk == 0) {
             int total = 0;
             for (int gi = 0; gi < d.n_good; ++gi)
-              for (int ai = 0; ai < d.n_adv; ++ai) total += hit(d.good_list[gi], d.adv_list[ai]) ? 1 : 0;
+              for (int ai = 0; ai < d.n_adv; ++ai) total += hit(desc_u8(d.good_list, gi), desc_u8(d.adv_list, ai)) ? 1 : 0;
             const double s_t = group_sum(active ? (double)total : 0.0, TILE);
             const double s_n = group_sum(active ? 1.0 : 0.0, TILE);
             if (lane == 0) { srow[2 * A] += s_t; srow[2 * A + 1] += s_n; }
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           };
           int count = 0, bonus = 0, caught = 0;  // caught: (good, adversary) contacts
           for (int gi = 0; gi < d.n_good; ++gi) {
-            const int g = d.good_list[gi];
+            const int g = desc_u8(d.good_list, gi);
             for (int o = 0; o < A; ++o) {
               if (o == g) continue;
               const int h = hit(g, o) ? 1 : 0;
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           for (int i = chunk; i < A; i += NCH) {
             const T pix = sPos[(2 * i) * TILE + lane], piy = sPos[(2 * i + 1) * TILE + lane];
             const bool lead = bit(d.advleader, i), super = bit(d.advsuper, i);
-            const int fi = d.force_id[i];
+            const int fi = desc_i8(d.force_id, i);
             // every term of the reference's running sum is +10 (or +1): exact in T, order-free
             int n = 0;
             T unit = T(10);
@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
             } else if (d.reward_variant == 1 && super) {
               // S1L2F2_10Targets_wide_rewardFixed.py:127-137: is_observed(target, target) is 0 < obs_r
               unit = T(1);
-              for (int o = 0; o < A; ++o) n += (d.forced_id[o] == fi && T(0) < d.obs_r2[o]) ? L : 0;
+              for (int o = 0; o < A; ++o) n += (desc_i8(d.forced_id, o) == fi && T(0) < d.obs_r2[o]) ? L : 0;
             } else {
-              for (int o = 0; o < A; ++o) n += d.forced_id[o] == fi ? sCnt[o * TILE + lane] : 0;  // :171-175
+              for (int o = 0; o < A; ++o) n += desc_i8(d.forced_id, o) == fi ? sCnt[o * TILE + lane] : 0;  // :171-175
             }
             T r_i = unit * T(n);
             r_i = r_i - tag_bound<T>(t_abs<T>(pix));  // :183-193
@@ -1053,13 +1053,13 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
           T m = T(0), adv_rew = T(0);
           if (has_goal) {
             for (int gi = 0; gi < d.n_good; ++gi) {
-              const int g = d.good_list[gi];
+              const int g = desc_u8(d.good_list, gi);
               const T dist = t_sqrt<T>(sqdist<T>(sPos[(2 * g) * TILE + lane], sPos[(2 * g + 1) * TILE + lane], gx, gy));
               m = (gi == 0 || dist < m) ? dist : m;
             }
             if (kind == MPE_SIMPLE_ADVERSARY)
               for (int ai = 0; ai < d.n_adv; ++ai) {
-                const int a = d.adv_list[ai];
+                const int a = desc_u8(d.adv_list, ai);
                 adv_rew = adv_rew + t_sqrt<T>(sqdist<T>(sPos[(2 * a) * TILE + lane], sPos[(2 * a + 1) * TILE + lane], gx, gy));
               }
           }
