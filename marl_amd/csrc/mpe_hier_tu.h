@@ -11,8 +11,9 @@ namespace mpe {
 
 template <typename T, int A, int L, int NF, bool DO_STEP, bool DO_OBS>
 static int launch_hier(const KParams<T> &p, hipStream_t s) {
-  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
-  hipLaunchKernelGGL((hier_kernel<T, A, L, NF, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  constexpr int TH = hier_threads((int)sizeof(T));
+  const dim3 grid((unsigned)((p.B + TH - 1) / TH)), block(TH);
+  hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS>), grid, block, 0, s, p);
   return (int)hipGetLastError();
 }
 
@@ -44,7 +45,8 @@ static int launch_hier_split_id(SmallId sv, const KParams<T> &p, hipStream_t s) 
 template <typename T, bool DO_STEP, bool DO_OBS>
 int launch_hier_id(SmallId sv, const KParams<T> &p, bool split, hipStream_t s) {
   if (split) return launch_hier_split_id<T, DO_STEP, DO_OBS>(sv, p, s);
-  const dim3 grid((unsigned)((p.B + kSmallThreads - 1) / kSmallThreads)), block(kSmallThreads);
+  constexpr int TH = hier_threads((int)sizeof(T));
+  const dim3 grid((unsigned)((p.B + TH - 1) / TH)), block(TH);
   switch (sv) {
     case HIER_3_3_2: return launch_hier<T, 3, 3, 2, DO_STEP, DO_OBS>(p, s);
     case HIER_5_3_4: return launch_hier<T, 5, 3, 4, DO_STEP, DO_OBS>(p, s);
@@ -54,10 +56,10 @@ int launch_hier_id(SmallId sv, const KParams<T> &p, bool split, hipStream_t s) {
     case HIER_5_3_2: return launch_hier<T, 5, 3, 2, DO_STEP, DO_OBS>(p, s);
     case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
     case MOVING_6_4_3:
-      hipLaunchKernelGGL((moving_kernel<T, 6, 4, 3, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((moving_kernel<T, 6, 4, 3, TH, DO_STEP, DO_OBS>), grid, block, 0, s, p);
       return (int)hipGetLastError();
     case MOVING_8_4_7:
-      hipLaunchKernelGGL((moving_kernel<T, 8, 4, 7, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((moving_kernel<T, 8, 4, 7, TH, DO_STEP, DO_OBS>), grid, block, 0, s, p);
       return (int)hipGetLastError();
     default: return MPE_ERR_UNSUPPORTED;
   }

@@ -450,6 +450,7 @@ static int small_launch_threads(const mpe_scenario_desc *h, int64_t B, int dtype
   if (sv == SMALL_PUSH_10_1) return dtype_bytes == 4 ? kSmallThreads : 0;
   if (small_id_splits(sv, B, flags)) return kSplitEnvs;
   if (hier_id_splits(sv, B, flags)) return hier_split_envs(sv);
+  if (small_id_is_hier(sv)) return hier_threads(dtype_bytes);
   return kSmallThreads;
 }
 

@@ -39,6 +39,11 @@ inline bool small_id_splits(SmallId sv, int64_t B, uint32_t flags) {
   if (flags & MPE_FLAG_SPLIT) return true;
   return !(flags & MPE_FLAG_WIDE) && B <= (int64_t)MPE_SPLIT_MAX_ENVS;
 }
+// Workgroup of the one-env-per-lane hierarchy / moving-target kernels in f64 (statistics rows follow it)
+#ifndef MPE_HIER_F64_THREADS
+#define MPE_HIER_F64_THREADS 256
+#endif
+constexpr int hier_threads(int dtype_bytes) { return dtype_bytes == 8 ? MPE_HIER_F64_THREADS : kSmallThreads; }
 constexpr int kHierDimC = 7;        // stock shape of the L1F* / S1L* Targets files
 constexpr int kHierTargets = 3;
 
