@@ -100,10 +100,12 @@ def measured_pmc(workload):
         return {}
     ks = json.load(open(path))['kernels']
 
-    def is_fused(name):      # template tails: small/hier <..., DO_STEP, DO_OBS>, tile <..., DO_STEP, DO_OBS, HIER[, KIND]>
+    def is_fused(name):      # template tails: small/hier <..., DO_STEP, DO_OBS[, RES]>, tile <..., DO_STEP, DO_OBS, HIER[, KIND]>
         args = name[name.index('<') + 1:name.rindex('>(')].split(', ')
         if 'tile_kernel' in name:
             return args[3:5] == ['true', 'true']
+        if args[-1].isdigit():                   # the Infinity Cache variant of the fused kernel (mpe_residency_plan)
+            args = args[:-1]
         return args[-2:] == ['true', 'true']
     fused = [v for k, v in ks.items() if 'mpe::' in k and is_fused(k)]
     return fused[0] if fused else {}

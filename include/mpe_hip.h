@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 10
+#define MPE_ABI_VERSION 11
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -232,6 +232,16 @@ const char *mpe_strerror(int code);
 /* sizeof(mpe_scenario_desc) as compiled into the library (bindings check their struct layout). */
 int64_t mpe_desc_sizeof(void);
 int64_t mpe_buffers_sizeof(void);
+
+/* Diagnostic (no reference counterpart): which state rows the fused one-env-per-lane register kernels (stock shapes of
+ * every scenario) stream past the 256 MiB Infinity Cache at row stride `ld` (elements): bit 0 landmark positions, bit 1
+ * velocities (command-hierarchy / moving-target kernels only), bit 2 leader_force.  While the whole state fits the cache
+ * every state load of a step is a hit; well beyond it the read-only landmark rows are read with nontemporal loads so that
+ * the rows a step reads AND writes keep their place, and the velocities follow when positions + velocities overflow it
+ * while the positions alone still fit.  Cache policy only: results do not depend on it (tests compare the variants bit
+ * for bit).  simple_tag f32, 4 Mi envs: 401 -> 326 us per step; S1L2F2_10Targets f64, 1 Mi envs: 450 -> 427.
+ * Negative = error code. */
+int mpe_residency_plan(const mpe_scenario_desc *desc, int64_t ld, int dtype_bytes);
 
 /* Validates a descriptor (counts, positive masses/margin, what the kind supports). */
 int mpe_desc_check(const mpe_scenario_desc *desc);

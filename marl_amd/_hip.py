@@ -26,7 +26,7 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 10
+ABI_VERSION = 11
 FLAG_FORCE_TILE = 1
 FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
 FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
@@ -180,6 +180,8 @@ def _load():
     L.mpe_desc_sizeof.argtypes = []
     L.mpe_buffers_sizeof.restype = i64
     L.mpe_buffers_sizeof.argtypes = []
+    L.mpe_residency_plan.restype = ci
+    L.mpe_residency_plan.argtypes = [C.POINTER(ScenarioDesc), i64, ci]
     if L.mpe_abi_version() != ABI_VERSION:
         raise ImportError('marl_amd: libmpe_hip.so ABI %d != expected %d' % (L.mpe_abi_version(), ABI_VERSION))
     if L.mpe_desc_sizeof() != C.sizeof(ScenarioDesc):

@@ -74,6 +74,7 @@ struct KParams {
   double *stats;
   int64_t B, ld;
   uint32_t flags;  // mpe_buffers.flags (MPE_FLAG_*): the kernels read MPE_FLAG_SILENT_COMM_ZERO, MPE_FLAG_DEVICE_NOISE
+  uint32_t resid;  // kResid*: which state rows of this launch bypass the Infinity Cache (residency_plan, below)
   // in-kernel u_noise / c_noise normals (MPE_FLAG_DEVICE_NOISE): Philox key, step counter (+ *nstep_dev when not
   // NULL: the word a HIP-graph replay moves), global id of env 0 of this call
   uint32_t nk0, nk1, nstep;
@@ -81,6 +82,50 @@ struct KParams {
   uint64_t env_id0;
   DevDesc<T> d;
 };
+
+// Which state rows stay in the 256 MiB Infinity Cache between steps.  The env state is re-read by the next step; while
+// all of it fits, every state load is a cache hit (simple_tag, 1 Mi envs f32: 84 MB), and rows a step only WRITES
+// (leader_force: read by nobody but a later observe-only call) are overwritten in the cache step after step without
+// ever reaching HBM.  Beyond the cache a sweep over all rows hits less and less, and it pays to send some rows past it
+// with nontemporal accesses so that the others keep their place: first the write-only leader_force rows, then the
+// READ-ONLY rows (fixed landmarks / targets), and the velocities when positions + velocities overflow the cache while
+// the positions alone still fit (residency_plan, below).  Measured, one env per lane, plan on vs off on one box
+// (tools/small_batch.sh, kernel us per step):
+//   S1L2F2_10Targets f64 1 Mi envs (state 336 MB + 84 MB leader_force)  462 -> 427     2 Mi: 943 -> 894    f32 2 Mi: 420 -> 392
+//   S1L2F4_MovingTarget f64 1 Mi envs (268 MB + 134 MB leader_force)     711 -> 637     2 Mi: 1479 -> 1413
+//   simple_world_comm f64 1 Mi envs (285 MB)  444 -> 420      simple_tag f32 4 Mi envs (335 MB)  401 -> 326
+//   simple_tag f64 2 Mi envs  383 -> 324       L1F2_3Targets f64 2 Mi envs  412 -> 394
+// and where everything fits, streaming loses (S1L2F2_10Targets f64 512 Ki envs, targets streamed: 217.6 -> 226.0 us; f32
+// 1 Mi envs, leader_force streamed: 186 -> 191; S1L2F4_MovingTarget f32 1 Mi envs: 305 -> 318), hence a plan per launch
+// instead of a fixed policy.
+constexpr uint32_t kResidNtLandmarks = 1u, kResidNtVel = 2u, kResidNtLforce = 4u;
+#ifndef MPE_RESID_BUDGET_MB
+#define MPE_RESID_BUDGET_MB 250
+#endif
+#ifndef MPE_RESID_SHED_MB
+#define MPE_RESID_SHED_MB 300
+#endif
+// Kernel variants (template parameter RES of the fused one-env-per-lane kernels): 0 everything cached, 1 leader_force
+// streamed, 2 + landmarks, 3 + velocities.
+inline int resid_variant(uint32_t plan) {
+  return (plan & kResidNtVel) ? 3 : ((plan & kResidNtLandmarks) ? 2 : ((plan & kResidNtLforce) ? 1 : 0));
+}
+inline uint32_t residency_plan(int A, int L, bool has_lforce, int64_t ld, int elem_bytes) {
+  const double row = (double)ld * elem_bytes, mib = 1048576.0;
+  const double budget = MPE_RESID_BUDGET_MB * mib;  // what read-only rows may fill up
+  const double shed = MPE_RESID_SHED_MB * mib;      // beyond this much read-write state the velocities are streamed
+  const double pos = 2.0 * A * row, vel = 2.0 * A * row, lm = 2.0 * L * row;
+  uint32_t plan = 0;
+  // velocities: streamed when positions + velocities overflow the cache but the positions alone still (mostly) fit.
+  // S1L2F4_MovingTarget f64, streamed vs cached: 1 Mi envs (134 + 134 MB) 679 vs 636 us -- the cache still serves most of
+  // a 268 MB sweep --, 2 Mi envs (268 + 268 MB) 1413 vs 1479; S1L2F2_10Targets f64 2 Mi envs (168 + 168 MB) 894 vs 934;
+  // positions alone past the cache (S1L2F4_MovingTarget f64 4 Mi envs, 537 MB): 3400 vs 3345, nothing left to protect.
+  if (pos + vel > shed && pos <= shed) plan |= kResidNtVel;
+  const double used = pos + ((plan & kResidNtVel) ? 0.0 : vel);
+  if (L > 0 && used + lm > budget) plan |= kResidNtLandmarks;  // read-only rows go first
+  if (has_lforce && (plan != 0 || used + lm + 2.0 * A * row > budget)) plan |= kResidNtLforce;
+  return plan;
+}
 
 // agent.state.c of a SILENT agent is zeros(dim_c) after every step (core.py:226-227).  A caller whose comm buffer already
 // holds zeros in those rows says so with MPE_FLAG_SILENT_COMM_ZERO and the step leaves them alone: in the hierarchy worlds
@@ -178,6 +223,19 @@ struct Win {
   }
   __device__ __forceinline__ void st_stream(int row, uint32_t lane, T v) const {
     if (lane != kNoLane) mpe::st_stream(at(row, lane), v);
+  }
+  // state rows whose cache policy the launch decides (residency_plan): NT is a compile-time constant of the kernel
+  // variant.  (A run-time `nt ? ld_stream : ld_state` does not survive the compiler: the two accesses to one address are
+  // merged into one plain access and the hint is gone.)
+  template <bool NT>
+  __device__ __forceinline__ T ld_state_nt(int row, uint32_t lane) const {
+    if constexpr (NT) return ld_stream(row, lane);
+    else return ld_state(row, lane);
+  }
+  template <bool NT>
+  __device__ __forceinline__ void st_state_nt(int row, uint32_t lane, T v) const {
+    if constexpr (NT) st_stream(row, lane, v);
+    else st_state(row, lane, v);
   }
 };
 

@@ -44,7 +44,7 @@ constexpr bool kHierRollF64 = true;
 //
 // EREG: how many entity positions sit in the px / py registers: all E, or only the A agents when the targets are kept in
 // LDS (hier_kernel, L >= kHierLdsTargets); then tgt(l, component) reads target l of this lane's env.
-template <typename T, int A, int E, int NF, int NG, int C, bool DO_STEP, bool DO_OBS, int EREG, typename TgtFn>
+template <typename T, int A, int E, int NF, int NG, int C, bool DO_STEP, bool DO_OBS, int EREG, int RES, typename TgtFn>
 __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk0, const uint32_t lo, T (&px)[EREG],
                                           T (&py)[EREG], T (&vx)[A], T (&vy)[A], T (&lfx)[A], T (&lfy)[A], TgtFn tgt) {
   static_assert(EREG == E || EREG == A, "all entities in registers, or the agents only");
@@ -181,13 +181,13 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
     for (int a = 0; a < A; ++a) {
       px[a] = npx[a];
       py[a] = npy[a];
-      wvel.st_state(2 * a, lo, vx[a]);
-      wvel.st_state(2 * a + 1, lo, vy[a]);
+      wvel.template st_state_nt<(RES >= 3)>(2 * a, lo, vx[a]);
+      wvel.template st_state_nt<(RES >= 3)>(2 * a + 1, lo, vy[a]);
       wpos.st_state(2 * a, lo, px[a]);
       wpos.st_state(2 * a + 1, lo, py[a]);
-      if (p.lforce != nullptr) {
-        wlf.st_state(2 * a, lo, lfx[a]);
-        wlf.st_state(2 * a + 1, lo, lfy[a]);
+      if (p.lforce != nullptr) {  // (read again only by an observe-only call)
+        wlf.template st_state_nt<(RES >= 1)>(2 * a, lo, lfx[a]);
+        wlf.template st_state_nt<(RES >= 1)>(2 * a + 1, lo, lfy[a]);
       }
     }
   } else if (DO_OBS && p.lforce != nullptr) {
@@ -202,7 +202,8 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
 
 }
 
-template <typename T, int A, int L, int NF, int THREADS, bool DO_STEP, bool DO_OBS>
+// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan / resid_variant)
+template <typename T, int A, int L, int NF, int THREADS, bool DO_STEP, bool DO_OBS, int RES = 0>
 __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr int C = kHierDimC;
@@ -222,23 +223,28 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
   __shared__ T sT[TLDS ? 2 * L : 1][TLDS ? THREADS : 1];
   T px[EREG], py[EREG], vx[A], vy[A], lfx[A], lfy[A];
 #pragma unroll
-  for (int e = 0; e < EREG; ++e) {
+  for (int e = 0; e < A; ++e) {
     px[e] = wpos.ld_state(2 * e, lo);
     py[e] = wpos.ld_state(2 * e + 1, lo);
   }
+#pragma unroll
+  for (int e = A; e < EREG; ++e) {
+    px[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e, lo);
+    py[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e + 1, lo);
+  }
   if constexpr (TLDS) {
 #pragma unroll
-    for (int r = 0; r < 2 * L; ++r) sT[r][threadIdx.x] = wpos.ld_state(2 * A + r, lo);
+    for (int r = 0; r < 2 * L; ++r) sT[r][threadIdx.x] = wpos.template ld_state_nt<(RES >= 2)>(2 * A + r, lo);
   }
   auto tgt = [&](int l, int c) -> T { return sT[TLDS ? 2 * l + c : 0][TLDS ? threadIdx.x : 0]; };
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = wvel.ld_state(2 * a, lo);
-    vy[a] = wvel.ld_state(2 * a + 1, lo);
+    vx[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a, lo);
+    vy[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a + 1, lo);
     lfx[a] = lfy[a] = T(0);
   }
 
-  hier_step<T, A, E, NF, 0, C, DO_STEP, DO_OBS, EREG>(p, blk0, lo, px, py, vx, vy, lfx, lfy, tgt);
+  hier_step<T, A, E, NF, 0, C, DO_STEP, DO_OBS, EREG, RES>(p, blk0, lo, px, py, vx, vy, lfx, lfy, tgt);
 
   if (DO_OBS) {
     const bool want_obs = p.obs != nullptr, want_rew = p.rew != nullptr, want_info = p.info != nullptr,
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
 #ifndef MPE_MOVING_ATTR
 #define MPE_MOVING_ATTR __attribute__((amdgpu_waves_per_eu(1, MPE_MOVING_CAP)))
 #endif
-template <typename T, int A, int NF, int C, int THREADS, bool DO_STEP, bool DO_OBS>
+template <typename T, int A, int NF, int C, int THREADS, bool DO_STEP, bool DO_OBS, int RES = 0>
 __global__ __launch_bounds__(THREADS) MPE_MOVING_ATTR void moving_kernel(const KParams<T> p) {
   constexpr int E = A, G = A - 1;  // G: the prey
   const DevDesc<T> &d = p.d;
@@ -454,11 +460,11 @@ __global__ __launch_bounds__(THREADS) MPE_MOVING_ATTR void moving_kernel(const K
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = wvel.ld_state(2 * a, lo);
-    vy[a] = wvel.ld_state(2 * a + 1, lo);
+    vx[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a, lo);
+    vy[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a + 1, lo);
     lfx[a] = lfy[a] = T(0);
   }
-  hier_step<T, A, E, NF, 1, C, DO_STEP, DO_OBS, E>(p, blk0, lo, px, py, vx, vy, lfx, lfy, [](int, int) { return T(0); });
+  hier_step<T, A, E, NF, 1, C, DO_STEP, DO_OBS, E, RES>(p, blk0, lo, px, py, vx, vy, lfx, lfy, [](int, int) { return T(0); });
 
   if (DO_OBS) {
     const bool want_rew = p.rew != nullptr, want_info = p.info != nullptr, want_stats = p.stats != nullptr;

@@ -13,7 +13,27 @@ template <typename T, int A, int L, int NF, bool DO_STEP, bool DO_OBS>
 static int launch_hier(const KParams<T> &p, hipStream_t s) {
   constexpr int TH = hier_threads((int)sizeof(T));
   const dim3 grid((unsigned)((p.B + TH - 1) / TH)), block(TH);
-  hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS>), grid, block, 0, s, p);
+  // the fused step has one variant per Infinity Cache plan (mpe_device.h:residency_plan)
+  const int res = (DO_STEP && DO_OBS) ? resid_variant(p.resid) : 0;
+  if constexpr (DO_STEP && DO_OBS) {
+    if (res == 3) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 3>), grid, block, 0, s, p);
+    else if (res == 2) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 2>), grid, block, 0, s, p);
+    else if (res == 1) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 1>), grid, block, 0, s, p);
+  }
+  if (res == 0) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 0>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+template <typename T, int A, int NF, int C, bool DO_STEP, bool DO_OBS>
+static int launch_moving(const KParams<T> &p, hipStream_t s) {
+  constexpr int TH = hier_threads((int)sizeof(T));
+  const dim3 grid((unsigned)((p.B + TH - 1) / TH)), block(TH);
+  const int res = (DO_STEP && DO_OBS) ? resid_variant(p.resid) : 0;
+  if constexpr (DO_STEP && DO_OBS) {  // no landmarks: variants 1 and 2 are the same kernel
+    if (res == 3) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 3>), grid, block, 0, s, p);
+    else if (res >= 1) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 1>), grid, block, 0, s, p);
+  }
+  if (res == 0) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 0>), grid, block, 0, s, p);
   return (int)hipGetLastError();
 }
 
@@ -45,8 +65,6 @@ static int launch_hier_split_id(SmallId sv, const KParams<T> &p, hipStream_t s) 
 template <typename T, bool DO_STEP, bool DO_OBS>
 int launch_hier_id(SmallId sv, const KParams<T> &p, bool split, hipStream_t s) {
   if (split) return launch_hier_split_id<T, DO_STEP, DO_OBS>(sv, p, s);
-  constexpr int TH = hier_threads((int)sizeof(T));
-  const dim3 grid((unsigned)((p.B + TH - 1) / TH)), block(TH);
   switch (sv) {
     case HIER_3_3_2: return launch_hier<T, 3, 3, 2, DO_STEP, DO_OBS>(p, s);
     case HIER_5_3_4: return launch_hier<T, 5, 3, 4, DO_STEP, DO_OBS>(p, s);
@@ -55,12 +73,8 @@ int launch_hier_id(SmallId sv, const KParams<T> &p, bool split, hipStream_t s) {
     case HIER_3_10_1: return launch_hier<T, 3, 10, 1, DO_STEP, DO_OBS>(p, s);
     case HIER_5_3_2: return launch_hier<T, 5, 3, 2, DO_STEP, DO_OBS>(p, s);
     case HIER_5_10_2: return launch_hier<T, 5, 10, 2, DO_STEP, DO_OBS>(p, s);
-    case MOVING_6_4_3:
-      hipLaunchKernelGGL((moving_kernel<T, 6, 4, 3, TH, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-      return (int)hipGetLastError();
-    case MOVING_8_4_7:
-      hipLaunchKernelGGL((moving_kernel<T, 8, 4, 7, TH, DO_STEP, DO_OBS>), grid, block, 0, s, p);
-      return (int)hipGetLastError();
+    case MOVING_6_4_3: return launch_moving<T, 6, 4, 3, DO_STEP, DO_OBS>(p, s);
+    case MOVING_8_4_7: return launch_moving<T, 8, 4, 7, DO_STEP, DO_OBS>(p, s);
     default: return MPE_ERR_UNSUPPORTED;
   }
 }

@@ -459,14 +459,24 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, uint32_t flag
   SmallId sv;
   const int threads = small_launch_threads(h, p.B, (int)sizeof(T), flags, &sv);
   if (threads != 0) {
-    if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, p, hier_id_splits(sv, p.B, flags), s);
+    KParams<T> q = p;  // the one-env-per-lane kernels follow the launch's residency plan (mpe_device.h)
+    q.resid = residency_plan(h->n_agents, h->n_landmarks, p.lforce != nullptr, p.ld, (int)sizeof(T));
+    if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, q, hier_id_splits(sv, p.B, flags), s);
     int noise = 0;  // 1: the caller's normals, 2: drawn in the kernel (MPE_FLAG_DEVICE_NOISE)
     if (DO_STEP && (p.noise != nullptr || (flags & MPE_FLAG_DEVICE_NOISE)))
       for (int a = 0; a < h->n_agents; ++a)
         if (h->u_noise[a] != 0.0) noise = p.noise != nullptr ? 1 : 2;
-    return launch_stock_id<T, DO_STEP, DO_OBS>(sv, p, noise, small_id_splits(sv, p.B, flags), s);
+    return launch_stock_id<T, DO_STEP, DO_OBS>(sv, q, noise, small_id_splits(sv, p.B, flags), s);
   }
   return launch_tile_world<T, DO_STEP, DO_OBS>(h, p, s);
+}
+
+extern "C" int mpe_residency_plan(const mpe_scenario_desc *h, int64_t ld, int dtype_bytes) {
+  int rc = mpe_desc_check(h);
+  if (rc) return rc;
+  if (ld < 1) return MPE_ERR_BATCH;
+  if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
+  return (int)residency_plan(h->n_agents, h->n_landmarks, has_lforce(h), ld, dtype_bytes);
 }
 
 extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, uint32_t flags) {

@@ -48,7 +48,8 @@ constexpr int small_wave_cap(int kind, int elem_bytes) {
 #endif
 
 // NOISE: 0 = no u_noise, 1 = the caller's normals (p.noise), 2 = drawn in the kernel (MPE_FLAG_DEVICE_NOISE, mpe_device.h)
-template <typename T, int KIND, int A, int L, int NADV, int THREADS, int NOISE, bool DO_STEP, bool DO_OBS>
+// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan); 2 = the landmark rows are streamed past the cache
+template <typename T, int KIND, int A, int L, int NADV, int THREADS, int NOISE, bool DO_STEP, bool DO_OBS, int RES = 0>
 __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
   constexpr bool TAG = KIND == MPE_SIMPLE_TAG;
@@ -65,9 +66,14 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
   T px[E], py[E], vx[A], vy[A];
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
+  for (int e = 0; e < A; ++e) {
     px[e] = wpos.ld_state(2 * e, lo);
     py[e] = wpos.ld_state(2 * e + 1, lo);
+  }
+#pragma unroll
+  for (int e = A; e < E; ++e) {  // fixed landmarks: read-only rows
+    px[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e, lo);
+    py[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e + 1, lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {

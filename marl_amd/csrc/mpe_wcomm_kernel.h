@@ -15,7 +15,8 @@ namespace mpe {
 #ifndef MPE_WCOMM_CAP
 #define MPE_WCOMM_CAP 2  // 1Mi envs f32: 217.3 us at 4, 208.9 at 3, 203.6 at 2 (320 rows per wavefront)
 #endif
-template <typename T, int THREADS, bool DO_STEP, bool DO_OBS>
+// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan); 2 = the landmark rows are streamed past the cache
+template <typename T, int THREADS, bool DO_STEP, bool DO_OBS, int RES = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_WCOMM_CAP))) void wcomm_kernel(const KParams<T> p) {
   constexpr int A = 6, NADV = 4, L = 5, E = A + L, ECOL = A + 1, C = 4;
   constexpr int FOOD0 = A + 1, FOOD1 = A + 3, FOREST0 = A + 3;
@@ -29,9 +30,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
   const Win<T> wpos(p.pos + blk0, ld), wvel(p.vel + blk0, ld);
   T px[E], py[E], vx[A], vy[A], c0[C];
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
+  for (int e = 0; e < A; ++e) {
     px[e] = wpos.ld_state(2 * e, lo);
     py[e] = wpos.ld_state(2 * e + 1, lo);
+  }
+#pragma unroll
+  for (int e = A; e < E; ++e) {  // fixed landmarks: read-only rows
+    px[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e, lo);
+    py[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e + 1, lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {

@@ -316,6 +316,39 @@ def test_agent_per_wavefront_form_equals_env_per_lane_form(golden_dir, base, dty
     assert sw[2 * A + 1] == 4 * B and sw[A:2 * A + 1].sum() > 0           # target hits / prey contacts happened
 
 
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('base', ['S1L2F2_10Targets_wide', 'S1L2F4_MovingTarget', 'L1F2_3Targets_100observe'])
+def test_residency_variants_bit_identical(golden_dir, base, dtype):
+    """The fused one-env-per-lane kernels have one variant per Infinity Cache plan (mpe_residency_plan: which state rows are
+    read and written with nontemporal accesses).  The plan follows the row stride, so a small batch inside wide rows runs
+    the variants of multi-million-env launches: every output equal bit for bit to the run at ld = B."""
+    spec = _spec_of(golden_dir, base)
+    A, B = spec.n_agents, 777
+    nbytes = 8 if dtype == torch.float64 else 4
+    _, pos, vel, lf0, acts = _rand_rollout(spec, B, dtype, 3, 41)
+    res, plans = [], []
+    try:
+        set_call_flags(WIDE)
+        for ld in [B] + [k * (1 if dtype == torch.float64 else 2) * 1048576 + 128 for k in (1, 2)]:
+            sim = HipSim(spec, B, dtype, ld)
+            plans.append(lib.mpe_residency_plan(sim.desc, ld, nbytes))
+            sim.set_state(pos, vel, lforce=lf0)
+            for t in range(3):
+                act = torch.zeros(sum(spec.act_dims), ld, dtype=dtype, device='cuda')
+                act[:, :B] = dev(acts[t], dtype)
+                sim.env_step(act)
+            res.append(list(sim.host()) + [sim.lforce[..., :B].cpu().numpy()])
+            assert torch.isnan(sim.obs[..., B:B + 64]).all() and (sim.pos[..., B:B + 64] == 0).all()
+            del sim, act
+            torch.cuda.empty_cache()
+    finally:
+        set_call_flags(0)
+    assert plans[0] == 0 and plans[-1] != 0 and (A < 5 or plans[-1] & 2)     # cached ... velocities streamed too (5 agents and more)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize('base', ['S1L2F2_10Targets_wide', 'S1L2F4_MovingTarget'])
 def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, base, force_tile):
     spec = _spec_of(golden_dir, base)

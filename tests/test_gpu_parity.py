@@ -586,3 +586,39 @@ def test_movable_landmark_through_the_public_api(golden_dir):
         np.testing.assert_allclose(torch.stack([lm.state.p_vel for lm in w.landmarks]).cpu().numpy(),
                                    np.moveaxis(g['lvel'][:, t], 0, 1), rtol=0, atol=1e-9)
         np.testing.assert_allclose(torch.cat(obs_n, 1).cpu().numpy(), g['obs'][:, t], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('mk', ['tag', 'world_comm', 'adversary', 'spread'])
+def test_residency_variants_of_the_stock_kernels_bit_identical(mk, dtype):
+    """The fused one-env-per-lane kernels stream their landmark rows past the Infinity Cache when the state outgrows it
+    (mpe_residency_plan follows the row stride): a small batch inside multi-million-element rows runs that variant, with
+    every output equal bit for bit to the run at ld = B."""
+    from tests.gpu_util import set_call_flags
+    spec = {'tag': O.simple_tag_spec, 'world_comm': O.simple_world_comm_spec, 'adversary': O.simple_adversary_spec,
+            'spread': O.simple_spread_spec}[mk]()
+    A, E, B = spec.n_agents, spec.n_entities, 515
+    nbytes = 8 if dtype == torch.float64 else 4
+    rng = np.random.RandomState(17)
+    pos, vel = rng.uniform(-0.4, 0.4, (E, 2, B)), rng.uniform(-0.5, 0.5, (A, 2, B))
+    goal = rng.randint(0, spec.n_landmarks, B)
+    acts = rng.rand(3, sum(spec.act_dims), B)
+    res, plans = [], []
+    try:
+        set_call_flags(2)                                                # MPE_FLAG_WIDE: one env per lane at this batch size too
+        for ld in (B, (6 if nbytes == 8 else 12) * 1048576 + 128):
+            sim = HipSim(spec, B, dtype, ld)
+            plans.append(lib.mpe_residency_plan(sim.desc, ld, nbytes))
+            sim.set_state(pos, vel, goal if spec.goal_rows else None)
+            for t in range(3):
+                act = torch.zeros(sum(spec.act_dims), ld, dtype=dtype, device='cuda')
+                act[:, :B] = dev(acts[t], dtype)
+                sim.env_step(act.view(A, 5, ld) if all(spec.silent) else act)
+            res.append(sim.host())
+            del sim, act
+            torch.cuda.empty_cache()
+    finally:
+        set_call_flags(0)
+    assert plans[0] == 0 and plans[1] & 1
+    for x, y in zip(*res):
+        assert np.array_equal(x, y, equal_nan=True)
