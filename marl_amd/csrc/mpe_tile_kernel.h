@@ -649,9 +649,9 @@ __global__ __launch_bounds__(THREADS) MPE_TILE_ATTR void tile_kernel(const KPara
               st_stream(o + ld, v ? sVel[(2 * j + 1) * TILE + lane] : T(0));
               o += 2 * ld;
             }
-            if (bit(d.obs_lf, i)) {
-              st_stream(o, sLf[(2 * i) * TILE + lane]);
-              st_stream(o + ld, sLf[(2 * i + 1) * TILE + lane]);
+            if (bit(d.obs_lf, i)) {  // (a world in which nobody is commanded keeps no leader_force rows: zeros, core.py:154)
+              st_stream(o, has_lf ? sLf[(2 * i) * TILE + lane] : T(0));
+              st_stream(o + ld, has_lf ? sLf[(2 * i + 1) * TILE + lane] : T(0));
             }
             continue;
           }

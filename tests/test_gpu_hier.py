@@ -349,6 +349,27 @@ def test_residency_variants_bit_identical(golden_dir, base, dtype):
             assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.parametrize('base', MOVING)
+def test_moving_world_in_which_nobody_is_commanded(golden_dir, base, force_tile):
+    """forced_id = -1 everywhere: no agent has a leader_force (the world keeps no such rows at all), yet the observations
+    of the *_MovingTarget files still end with it for the agents whose text says so: zeros (core.py:154).  Found by the
+    stock-shape fuzz: the tile kernel wrote velocity rows there."""
+    spec = _spec_of(golden_dir, base)
+    spec = dataclasses.replace(spec, forced_id=[-1] * spec.n_agents)
+    assert not spec.has_leader_force
+    B, steps = 1500 + 7, 3
+    _, pos, vel, _, acts = _rand_rollout(spec, B, torch.float64, steps, 5)
+    sim = HipSim(spec, B, torch.float64)
+    sim.set_state(pos, vel)
+    bo = O.BatchedOracle(spec)
+    for t in range(steps):
+        sim.env_step(dev(acts[t], torch.float64))
+        pos, vel, obs, rew, info = bo.env_step(pos, vel, acts[t])[:5]
+        gp, gv, go, gr, gi = sim.host()
+        errs = (_maxerr(gp, pos), _maxerr(gv, vel), _maxerr(go, np.concatenate(obs, 0)), _maxerr(gr, rew), _maxerr(gi, info))
+        assert max(errs) <= F64_TOL, (base, t, errs)
+
+
 @pytest.mark.parametrize('base', ['S1L2F2_10Targets_wide', 'S1L2F4_MovingTarget'])
 def test_stats_rows_accumulate_rewards_and_contacts(golden_dir, base, force_tile):
     spec = _spec_of(golden_dir, base)

@@ -169,7 +169,7 @@ def random_spec(rng, stock_only=False):
     return kind, dataclasses.replace(spec, **rep)
 
 
-def run(n_worlds, seed, perturb=0.0, stock_only=False):
+def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
     """-> (mismatching runs, worlds refused by mpe_desc_check, worlds per kind).  perturb != 0: the oracle steps a world
     whose damping differs by that much (negative control: the comparison must notice)."""
     rng = np.random.RandomState(seed)
@@ -274,13 +274,15 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False):
                           % (w, kind, A, spec.n_landmarks, nm, np.nanmax(np.abs(x - np.asarray(y).reshape(x.shape))), spec), flush=True)
                     break
         kernels[kind] = kernels.get(kind, 0) + 1
+        if progress and (w + 1) % progress == 0:
+            print('... %d worlds, %d mismatching runs so far' % (w + 1, bad), flush=True)
     return bad, refused, {str(k): v for k, v in kernels.items()}
 
 
 def main():
     n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, refused, kinds = run(n_worlds, seed, stock_only=len(sys.argv) > 3 and sys.argv[3] == 'stock')
+    bad, refused, kinds = run(n_worlds, seed, stock_only=len(sys.argv) > 3 and sys.argv[3] == 'stock', progress=500)
     print('worlds %d (refused by mpe_desc_check: %d), by kind %s, mismatching (world, kernel) runs: %d'
           % (n_worlds, refused, kinds, bad))
     sys.exit(1 if bad else 0)
