@@ -19,7 +19,7 @@ def test_random_worlds_match_the_oracle():
     assert bad == 0 and refused == 0
     bad, _, _ = mod.run(30, 1, perturb=1e-6)            # negative control: a 1e-6 change of the damping is noticed
     assert bad >= 50
-    assert set(kinds) == {'tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'wcomm', 'big', 'stock_hier'}
+    assert set(kinds) == {'tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'wcomm', 'big', 'stock_hier', 'moving'}
     assert min(kinds.values()) >= 20
 
 

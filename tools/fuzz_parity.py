@@ -2,7 +2,7 @@
 and random per-entity constants (sizes, masses, accel None or a value, max_speed None or a value, collide flags in
 irregular patterns, u_noise on some agents, damping / dt / contact constants), dense starts so that contacts happen.
 f64, every output of 3 steps within 1e-9 (NaN patterns equal).  Run on the GPU box from the repo root:
-    python tools/fuzz_parity.py [n_worlds] [seed] [stock]      (stock: only the shapes that have register kernels)
+    python tools/fuzz_parity.py [n_worlds] [seed] [stock|moving]      (stock: only the shapes that have register kernels; moving: only random *_MovingTarget-like worlds)
 Prints one line per mismatch or refusal and a summary; exit status 1 if anything differs."""
 import dataclasses
 import os
@@ -116,13 +116,49 @@ def random_stock_small(rng):
     return 'stock_small', dataclasses.replace(spec, **rep)
 
 
+def random_moving(rng):
+    """A *_MovingTarget-like world no scenario file builds (kind HIER_MOVING): silent followers, speaking leaders (one of
+    them possibly a super-leader), one prey as the last agent, no landmarks; random counts, links, radii, constants,
+    irregular collide flags, 3 or 7 commands, both files' observation / reward texts."""
+    A = int(rng.randint(3, 10))
+    pick = lambda p: rng.rand() < p
+    n_lead = int(rng.randint(1, max(2, (A - 1) // 2 + 1)))
+    G = A - 1
+    lead = [G - n_lead <= i < G for i in range(A)]
+    sup = [lead[i] and i == G - 1 and n_lead > 1 and pick(0.5) for i in range(A)]
+    force_id, forced_id = [-1] * A, [-1] * A
+    for i in range(G):
+        if lead[i] and not sup[i]:
+            force_id[i] = int(rng.choice([1, 2]))
+            if any(sup) and pick(0.5):
+                forced_id[i] = 3
+        elif sup[i]:
+            force_id[i] = 3
+        elif pick(0.8):
+            forced_id[i] = int(rng.choice([1, 2]))
+    return 'moving', O.ScenarioSpec(
+        kind=O.HIER_MOVING, n_agents=A, n_landmarks=0, adversary=[i < G for i in range(A)],
+        size=[float(rng.uniform(0.04, 0.15)) for _ in range(A)],
+        accel=[None if pick(0.2) else float(rng.uniform(2, 5)) for _ in range(A)],
+        max_speed=[None if pick(0.2) else float(rng.uniform(0.5, 1.5)) for _ in range(A)],
+        collide=[bool(pick(0.85)) for _ in range(A)], movable=[True] * A, u_noise=[None] * A,
+        mass=[float(rng.choice([1.0, 0.5, 2.0])) for _ in range(A)], agent_pos_range=1.0, landmark_pos_range=1.0,
+        dim_c=int(rng.choice([3, 7])), silent=[not lead[i] for i in range(A)], force_id=force_id, forced_id=forced_id,
+        advleader=lead, advsuperleader=sup, obs_r=[float(rng.uniform(0.15, 0.9)) for _ in range(A)],
+        reward_variant=int(rng.randint(0, 2)), n_target_obs=3)
+
+
 def random_spec(rng, stock_only=False):
+    if stock_only == 'moving':
+        return random_moving(rng)
     if stock_only and rng.rand() < 0.5:
         return random_stock_small(rng)
     kind = 'stock_hier' if stock_only else rng.choice(['tag', 'spread', 'simple', 'adversary', 'push', 'hier', 'hier',
-                                                       'wcomm', 'big', 'stock_hier'])
+                                                       'wcomm', 'big', 'stock_hier', 'moving'])
     if kind == 'hier':
         return random_hier(rng)
+    if kind == 'moving':
+        return random_moving(rng)
     if kind == 'stock_hier':
         return random_stock_hier(rng)
     if kind == 'tag':
@@ -282,7 +318,7 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
 def main():
     n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, refused, kinds = run(n_worlds, seed, stock_only=len(sys.argv) > 3 and sys.argv[3] == 'stock', progress=500)
+    bad, refused, kinds = run(n_worlds, seed, stock_only=(sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] == 'moving' else len(sys.argv) > 3 and sys.argv[3] == 'stock'), progress=500)
     print('worlds %d (refused by mpe_desc_check: %d), by kind %s, mismatching (world, kernel) runs: %d'
           % (n_worlds, refused, kinds, bad))
     sys.exit(1 if bad else 0)
