@@ -274,6 +274,23 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
                                       % (w, kind, A, spec.n_landmarks, flags, t, nm, err, np.isnan(x).sum(), np.isnan(y).sum(), spec),
                                       flush=True)
                             raise StopIteration
+                # the split entry points on the same world: mpe_world_step + mpe_observe == mpe_env_step bit for bit
+                parts = HipSim(spec, B, torch.float64)
+                parts.set_state(pos, vel, goal, lf0)
+                if lm_moves:
+                    parts.lvel.copy_(dev(lvel0, torch.float64))
+                comm = torch.zeros(A, max(spec.dim_c, 1), B, dtype=torch.float64, device='cuda')[:, :spec.dim_c]
+                for t in range(T):
+                    parts.world_step(dev(acts[t], torch.float64), dev(noises[t], torch.float64) if has_noise else None,
+                                     comm=comm if spec.dim_c else None)
+                    parts.observe(comm=comm if spec.dim_c else None)
+                for nm, x, y in zip(('pos', 'vel', 'obs', 'rew', 'info'), sim.host(), parts.host()):
+                    if not np.array_equal(x, y, equal_nan=True):
+                        bad += 1
+                        if not perturb:
+                            print('SPLIT ENTRY POINTS DIFFER world %d (%s A=%d L=%d) flags=%d %s   spec=%r'
+                                  % (w, kind, A, spec.n_landmarks, flags, nm, spec), flush=True)
+                        break
             except StopIteration:
                 pass
             finally:
