@@ -235,7 +235,8 @@ int64_t mpe_buffers_sizeof(void);
 
 /* Diagnostic (no reference counterpart): which state rows the fused one-env-per-lane register kernels (stock shapes of
  * every scenario) stream past the 256 MiB Infinity Cache at row stride `ld` (elements): bit 0 landmark positions, bit 1
- * velocities (command-hierarchy / moving-target kernels only), bit 2 leader_force.  While the whole state fits the cache
+ * velocities (command-hierarchy / moving-target kernels only), bit 2 leader_force, bit 3 the speaking agents' comm rows
+ * (assuming the call passes a comm buffer).  While the whole state fits the cache
  * every state load of a step is a hit; well beyond it the read-only landmark rows are read with nontemporal loads so that
  * the rows a step reads AND writes keep their place, and the velocities follow when positions + velocities overflow it
  * while the positions alone still fit.  Cache policy only: results do not depend on it (tests compare the variants bit

@@ -98,23 +98,24 @@ struct KParams {
 // and where everything fits, streaming loses (S1L2F2_10Targets f64 512 Ki envs, targets streamed: 217.6 -> 226.0 us; f32
 // 1 Mi envs, leader_force streamed: 186 -> 191; S1L2F4_MovingTarget f32 1 Mi envs: 305 -> 318), hence a plan per launch
 // instead of a fixed policy.
-constexpr uint32_t kResidNtLandmarks = 1u, kResidNtVel = 2u, kResidNtLforce = 4u;
+constexpr uint32_t kResidNtLandmarks = 1u, kResidNtVel = 2u, kResidNtLforce = 4u, kResidNtComm = 8u;
 #ifndef MPE_RESID_BUDGET_MB
 #define MPE_RESID_BUDGET_MB 250
 #endif
 #ifndef MPE_RESID_SHED_MB
 #define MPE_RESID_SHED_MB 300
 #endif
-// Kernel variants (template parameter RES of the fused one-env-per-lane kernels): 0 everything cached, 1 leader_force
-// streamed, 2 + landmarks, 3 + velocities.
+// Kernel variants (template parameter RES of the fused one-env-per-lane kernels): 0 everything cached, 1 the speaking
+// agents' comm rows streamed (write-only, like leader_force), 2 + leader_force, 3 + landmarks, 4 + velocities.
 inline int resid_variant(uint32_t plan) {
-  return (plan & kResidNtVel) ? 3 : ((plan & kResidNtLandmarks) ? 2 : ((plan & kResidNtLforce) ? 1 : 0));
+  return (plan & kResidNtVel) ? 4 : ((plan & kResidNtLandmarks) ? 3 : ((plan & kResidNtLforce) ? 2 : ((plan & kResidNtComm) ? 1 : 0)));
 }
-inline uint32_t residency_plan(int A, int L, bool has_lforce, int64_t ld, int elem_bytes) {
+inline uint32_t residency_plan(int A, int L, bool has_lforce, int comm_rows, int64_t ld, int elem_bytes) {
   const double row = (double)ld * elem_bytes, mib = 1048576.0;
-  const double budget = MPE_RESID_BUDGET_MB * mib;  // what read-only rows may fill up
+  const double budget = MPE_RESID_BUDGET_MB * mib;  // what read-only and write-only rows may fill up
   const double shed = MPE_RESID_SHED_MB * mib;      // beyond this much read-write state the velocities are streamed
   const double pos = 2.0 * A * row, vel = 2.0 * A * row, lm = 2.0 * L * row;
+  const double lf = has_lforce ? 2.0 * A * row : 0.0, comm = comm_rows * row;
   uint32_t plan = 0;
   // velocities: streamed when positions + velocities overflow the cache but the positions alone still (mostly) fit.
   // S1L2F4_MovingTarget f64, streamed vs cached: 1 Mi envs (134 + 134 MB) 679 vs 636 us -- the cache still serves most of
@@ -122,8 +123,13 @@ inline uint32_t residency_plan(int A, int L, bool has_lforce, int64_t ld, int el
   // positions alone past the cache (S1L2F4_MovingTarget f64 4 Mi envs, 537 MB): 3400 vs 3345, nothing left to protect.
   if (pos + vel > shed && pos <= shed) plan |= kResidNtVel;
   const double used = pos + ((plan & kResidNtVel) ? 0.0 : vel);
-  if (L > 0 && used + lm > budget) plan |= kResidNtLandmarks;  // read-only rows go first
-  if (has_lforce && (plan != 0 || used + lm + 2.0 * A * row > budget)) plan |= kResidNtLforce;
+  if (L > 0 && used + lm > budget) plan |= kResidNtLandmarks;  // read-only rows before read-write ones
+  const double cached = used + ((plan & kResidNtLandmarks) ? 0.0 : lm);
+  // write-only rows go first of all: the comm rows (S1L2F2_10Targets f32: cached vs streamed 98.7 vs 101.6 us at 512 Ki envs,
+  // where everything fits, 202 vs 188 at 1 Mi), then leader_force if that was not enough
+  const bool shedding = plan != 0;  // landmarks or velocities are streamed already
+  if (comm_rows > 0 && (shedding || cached + lf + comm > budget)) plan |= kResidNtComm;
+  if (has_lforce && (shedding || cached + lf > budget)) plan |= kResidNtLforce;
   return plan;
 }
 

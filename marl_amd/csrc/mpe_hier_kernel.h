@@ -126,6 +126,8 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
     if (p.comm != nullptr) {
       const Win<T> wcomm(p.comm + blk0, ld);
       const bool zeros = rewrite_silent_comm(p);
+      // the fused step follows the launch's Infinity Cache plan (RES >= 1: streamed); world_step alone keeps round 2's rule
+      constexpr bool NT_COMM = (DO_STEP && DO_OBS) ? (RES >= 1) : (A >= 5);
 #pragma unroll
       for (int a = 0; a < A; ++a) {
         const bool silent = a < NF || a >= LE;
@@ -133,8 +135,7 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
 #pragma unroll
         for (int k = 0; k < C; ++k) {
           const T v = silent ? T(0) : c[silent ? 0 : a - NF][k];
-          if (A >= 5) wcomm.st_stream(a * C + k, lo, v);
-          else wcomm.st_state(a * C + k, lo, v);
+          wcomm.template st_state_nt<NT_COMM>(a * C + k, lo, v);
         }
       }
     }
@@ -181,13 +182,13 @@ __device__ __forceinline__ void hier_step(const KParams<T> &p, const int64_t blk
     for (int a = 0; a < A; ++a) {
       px[a] = npx[a];
       py[a] = npy[a];
-      wvel.template st_state_nt<(RES >= 3)>(2 * a, lo, vx[a]);
-      wvel.template st_state_nt<(RES >= 3)>(2 * a + 1, lo, vy[a]);
+      wvel.template st_state_nt<(RES >= 4)>(2 * a, lo, vx[a]);
+      wvel.template st_state_nt<(RES >= 4)>(2 * a + 1, lo, vy[a]);
       wpos.st_state(2 * a, lo, px[a]);
       wpos.st_state(2 * a + 1, lo, py[a]);
       if (p.lforce != nullptr) {  // (read again only by an observe-only call)
-        wlf.template st_state_nt<(RES >= 1)>(2 * a, lo, lfx[a]);
-        wlf.template st_state_nt<(RES >= 1)>(2 * a + 1, lo, lfy[a]);
+        wlf.template st_state_nt<(RES >= 2)>(2 * a, lo, lfx[a]);
+        wlf.template st_state_nt<(RES >= 2)>(2 * a + 1, lo, lfy[a]);
       }
     }
   } else if (DO_OBS && p.lforce != nullptr) {
@@ -229,18 +230,18 @@ __global__ __launch_bounds__(THREADS) MPE_HIER_ATTR void hier_kernel(const KPara
   }
 #pragma unroll
   for (int e = A; e < EREG; ++e) {
-    px[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e, lo);
-    py[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e + 1, lo);
+    px[e] = wpos.template ld_state_nt<(RES >= 3)>(2 * e, lo);
+    py[e] = wpos.template ld_state_nt<(RES >= 3)>(2 * e + 1, lo);
   }
   if constexpr (TLDS) {
 #pragma unroll
-    for (int r = 0; r < 2 * L; ++r) sT[r][threadIdx.x] = wpos.template ld_state_nt<(RES >= 2)>(2 * A + r, lo);
+    for (int r = 0; r < 2 * L; ++r) sT[r][threadIdx.x] = wpos.template ld_state_nt<(RES >= 3)>(2 * A + r, lo);
   }
   auto tgt = [&](int l, int c) -> T { return sT[TLDS ? 2 * l + c : 0][TLDS ? threadIdx.x : 0]; };
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a, lo);
-    vy[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a + 1, lo);
+    vx[a] = wvel.template ld_state_nt<(RES >= 4)>(2 * a, lo);
+    vy[a] = wvel.template ld_state_nt<(RES >= 4)>(2 * a + 1, lo);
     lfx[a] = lfy[a] = T(0);
   }
 
@@ -460,8 +461,8 @@ __global__ __launch_bounds__(THREADS) MPE_MOVING_ATTR void moving_kernel(const K
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {
-    vx[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a, lo);
-    vy[a] = wvel.template ld_state_nt<(RES >= 3)>(2 * a + 1, lo);
+    vx[a] = wvel.template ld_state_nt<(RES >= 4)>(2 * a, lo);
+    vy[a] = wvel.template ld_state_nt<(RES >= 4)>(2 * a + 1, lo);
     lfx[a] = lfy[a] = T(0);
   }
   hier_step<T, A, E, NF, 1, C, DO_STEP, DO_OBS, E, RES>(p, blk0, lo, px, py, vx, vy, lfx, lfy, [](int, int) { return T(0); });

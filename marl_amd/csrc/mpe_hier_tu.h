@@ -16,7 +16,8 @@ static int launch_hier(const KParams<T> &p, hipStream_t s) {
   // the fused step has one variant per Infinity Cache plan (mpe_device.h:residency_plan)
   const int res = (DO_STEP && DO_OBS) ? resid_variant(p.resid) : 0;
   if constexpr (DO_STEP && DO_OBS) {
-    if (res == 3) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 3>), grid, block, 0, s, p);
+    if (res == 4) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 4>), grid, block, 0, s, p);
+    else if (res == 3) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 3>), grid, block, 0, s, p);
     else if (res == 2) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 2>), grid, block, 0, s, p);
     else if (res == 1) hipLaunchKernelGGL((hier_kernel<T, A, L, NF, TH, DO_STEP, DO_OBS, 1>), grid, block, 0, s, p);
   }
@@ -29,9 +30,10 @@ static int launch_moving(const KParams<T> &p, hipStream_t s) {
   constexpr int TH = hier_threads((int)sizeof(T));
   const dim3 grid((unsigned)((p.B + TH - 1) / TH)), block(TH);
   const int res = (DO_STEP && DO_OBS) ? resid_variant(p.resid) : 0;
-  if constexpr (DO_STEP && DO_OBS) {  // no landmarks: variants 1 and 2 are the same kernel
-    if (res == 3) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 3>), grid, block, 0, s, p);
-    else if (res >= 1) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 1>), grid, block, 0, s, p);
+  if constexpr (DO_STEP && DO_OBS) {  // no landmarks: variants 2 and 3 are the same kernel
+    if (res == 4) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 4>), grid, block, 0, s, p);
+    else if (res >= 2) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 2>), grid, block, 0, s, p);
+    else if (res == 1) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 1>), grid, block, 0, s, p);
   }
   if (res == 0) hipLaunchKernelGGL((moving_kernel<T, A, NF, C, TH, DO_STEP, DO_OBS, 0>), grid, block, 0, s, p);
   return (int)hipGetLastError();

@@ -78,6 +78,12 @@ static int goal_rows_of(const mpe_scenario_desc *h) {
   if (h->kind == MPE_SIMPLE_CRYPTO) return 2;  // goal landmark, landmark of the speaker's key
   return h->kind == MPE_SIMPLE_REFERENCE ? h->n_agents : 0;
 }
+// rows of agent.state.c a step writes: dim_c per speaking agent (core.py:226-230)
+static int speaking_comm_rows(const mpe_scenario_desc *h) {
+  int n = 0;
+  for (int a = 0; a < h->n_agents; ++a) n += h->silent[a] ? 0 : h->dim_c;
+  return n;
+}
 static bool has_lforce(const mpe_scenario_desc *h) {
   for (int a = 0; a < h->n_agents; ++a)
     if (h->forced_id[a] >= 0) return true;
@@ -460,7 +466,8 @@ static int launch(const mpe_scenario_desc *h, const KParams<T> &p, uint32_t flag
   const int threads = small_launch_threads(h, p.B, (int)sizeof(T), flags, &sv);
   if (threads != 0) {
     KParams<T> q = p;  // the one-env-per-lane kernels follow the launch's residency plan (mpe_device.h)
-    q.resid = residency_plan(h->n_agents, h->n_landmarks, p.lforce != nullptr, p.ld, (int)sizeof(T));
+    q.resid = residency_plan(h->n_agents, h->n_landmarks, p.lforce != nullptr, p.comm != nullptr ? speaking_comm_rows(h) : 0,
+                             p.ld, (int)sizeof(T));
     if (small_id_is_hier(sv)) return launch_hier_id<T, DO_STEP, DO_OBS>(sv, q, hier_id_splits(sv, p.B, flags), s);
     int noise = 0;  // 1: the caller's normals, 2: drawn in the kernel (MPE_FLAG_DEVICE_NOISE)
     if (DO_STEP && (p.noise != nullptr || (flags & MPE_FLAG_DEVICE_NOISE)))
@@ -476,7 +483,7 @@ extern "C" int mpe_residency_plan(const mpe_scenario_desc *h, int64_t ld, int dt
   if (rc) return rc;
   if (ld < 1) return MPE_ERR_BATCH;
   if (dtype_bytes != 4 && dtype_bytes != 8) return MPE_ERR_ARG;
-  return (int)residency_plan(h->n_agents, h->n_landmarks, has_lforce(h), ld, dtype_bytes);
+  return (int)residency_plan(h->n_agents, h->n_landmarks, has_lforce(h), speaking_comm_rows(h), ld, dtype_bytes);
 }
 
 extern "C" int64_t mpe_stats_rows(const mpe_scenario_desc *h, int64_t B, int dtype_bytes, uint32_t flags) {

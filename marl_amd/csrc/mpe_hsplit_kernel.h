@@ -93,18 +93,12 @@ __global__ __launch_bounds__(64 * EW * A) MPE_HSPLIT_ATTR void hier_split_kernel
       sK[me - NF][col] = C == 3 ? (k_best == 0 ? 0 : (k_best == 1 ? 5 : 6)) : k_best;
       sC[2 * (me - NF)][col] = c[0];
       sC[2 * (me - NF) + 1][col] = c[1];
-      if (p.comm != nullptr) {  // core.py:226-230 (agent.state.c = action.c); cache policy as in hier_step
+      if (p.comm != nullptr) {  // core.py:226-230 (agent.state.c = action.c); small batches: the rows stay in the cache
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-          if (A >= 5) wcomm.st_stream(me * C + k, lo, c[k]);
-          else wcomm.st_state(me * C + k, lo, c[k]);
-        }
+        for (int k = 0; k < C; ++k) wcomm.st_state(me * C + k, lo, c[k]);
       }
     } else if (p.comm != nullptr && rewrite_silent_comm(p)) {
-      for (int k = 0; k < C; ++k) {
-        if (A >= 5) wcomm.st_stream(me * C + k, lo, T(0));
-        else wcomm.st_state(me * C + k, lo, T(0));
-      }
+      for (int k = 0; k < C; ++k) wcomm.st_state(me * C + k, lo, T(0));
     }
   } else if (DO_OBS) {
     sN[4 * me + 0][col] = mpx;

@@ -48,7 +48,7 @@ constexpr int small_wave_cap(int kind, int elem_bytes) {
 #endif
 
 // NOISE: 0 = no u_noise, 1 = the caller's normals (p.noise), 2 = drawn in the kernel (MPE_FLAG_DEVICE_NOISE, mpe_device.h)
-// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan); 2 = the landmark rows are streamed past the cache
+// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan); 3 = the landmark rows are streamed past the cache
 template <typename T, int KIND, int A, int L, int NADV, int THREADS, int NOISE, bool DO_STEP, bool DO_OBS, int RES = 0>
 __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KParams<T> p) {
   constexpr int E = A + L;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(THREADS) MPE_SMALL_ATTR void small_kernel(const KPa
   }
 #pragma unroll
   for (int e = A; e < E; ++e) {  // fixed landmarks: read-only rows
-    px[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e, lo);
-    py[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e + 1, lo);
+    px[e] = wpos.template ld_state_nt<(RES >= 3)>(2 * e, lo);
+    py[e] = wpos.template ld_state_nt<(RES >= 3)>(2 * e + 1, lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {

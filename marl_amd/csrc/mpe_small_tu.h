@@ -26,8 +26,8 @@ static int launch_small(const KParams<T> &p, int noise, hipStream_t s) {
     }
   }
   if constexpr (DO_STEP && DO_OBS && L > 0) {  // the fused step has a variant that streams the landmark rows (residency_plan)
-    if (resid_variant(p.resid) >= 2) {
-      hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, 0, DO_STEP, DO_OBS, 2>), grid, block, 0, s, p);
+    if (resid_variant(p.resid) >= 3) {
+      hipLaunchKernelGGL((small_kernel<T, KIND, A, L, NADV, THREADS, 0, DO_STEP, DO_OBS, 3>), grid, block, 0, s, p);
       return (int)hipGetLastError();
     }
   }
@@ -67,8 +67,8 @@ int launch_stock_id(SmallId sv, const KParams<T> &p, int noise, bool split, hipS
     case COMM_SPEAKER_LISTENER: return launch_comm<T, MPE_SPEAKER_LISTENER, 3, DO_STEP, DO_OBS>(p, s);
     case COMM_REFERENCE: return launch_comm<T, MPE_SIMPLE_REFERENCE, 10, DO_STEP, DO_OBS>(p, s);
     case WCOMM_4_2_1_2_2:
-      if (DO_STEP && DO_OBS && resid_variant(p.resid) >= 2)
-        hipLaunchKernelGGL((wcomm_kernel<T, kSmallThreads, DO_STEP, DO_OBS, (DO_STEP && DO_OBS) ? 2 : 0>), grid, block, 0, s, p);
+      if (DO_STEP && DO_OBS && resid_variant(p.resid) >= 3)
+        hipLaunchKernelGGL((wcomm_kernel<T, kSmallThreads, DO_STEP, DO_OBS, (DO_STEP && DO_OBS) ? 3 : 0>), grid, block, 0, s, p);
       else
         hipLaunchKernelGGL((wcomm_kernel<T, kSmallThreads, DO_STEP, DO_OBS>), grid, block, 0, s, p);
       return (int)hipGetLastError();

@@ -15,7 +15,7 @@ namespace mpe {
 #ifndef MPE_WCOMM_CAP
 #define MPE_WCOMM_CAP 2  // 1Mi envs f32: 217.3 us at 4, 208.9 at 3, 203.6 at 2 (320 rows per wavefront)
 #endif
-// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan); 2 = the landmark rows are streamed past the cache
+// RES: the launch's Infinity Cache plan (mpe_device.h:residency_plan); 3 = the landmark rows are streamed past the cache
 template <typename T, int THREADS, bool DO_STEP, bool DO_OBS, int RES = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_WCOMM_CAP))) void wcomm_kernel(const KParams<T> p) {
   constexpr int A = 6, NADV = 4, L = 5, E = A + L, ECOL = A + 1, C = 4;
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, MPE_
   }
 #pragma unroll
   for (int e = A; e < E; ++e) {  // fixed landmarks: read-only rows
-    px[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e, lo);
-    py[e] = wpos.template ld_state_nt<(RES >= 2)>(2 * e + 1, lo);
+    px[e] = wpos.template ld_state_nt<(RES >= 3)>(2 * e, lo);
+    py[e] = wpos.template ld_state_nt<(RES >= 3)>(2 * e + 1, lo);
   }
 #pragma unroll
   for (int a = 0; a < A; ++a) {

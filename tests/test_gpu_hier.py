@@ -329,7 +329,7 @@ def test_residency_variants_bit_identical(golden_dir, base, dtype):
     res, plans = [], []
     try:
         set_call_flags(WIDE)
-        for ld in [B] + [k * (1 if dtype == torch.float64 else 2) * 1048576 + 128 for k in (1, 2)]:
+        for ld in [B] + [int(k * (1 if dtype == torch.float64 else 2) * 1048576) + 128 for k in (0.5, 0.65, 1, 2)]:
             sim = HipSim(spec, B, dtype, ld)
             plans.append(lib.mpe_residency_plan(sim.desc, ld, nbytes))
             sim.set_state(pos, vel, lforce=lf0)
@@ -344,6 +344,9 @@ def test_residency_variants_bit_identical(golden_dir, base, dtype):
     finally:
         set_call_flags(0)
     assert plans[0] == 0 and plans[-1] != 0 and (A < 5 or plans[-1] & 2)     # cached ... velocities streamed too (5 agents and more)
+    assert A < 5 or len(set(plans)) >= 3                                     # S1L2F2_10Targets: 0, 8, 12, 13, 15 = all five variants
+    if 'S1L2F2_10Targets' in base:
+        assert plans == [0, 8, 12, 13, 15]
     for other in res[1:]:
         for x, y in zip(res[0], other):
             assert np.array_equal(x, y, equal_nan=True)

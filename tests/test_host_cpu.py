@@ -371,20 +371,23 @@ def test_shared_force_id_between_super_leader_and_leader_is_refused():
 
 
 def test_residency_plan_of_the_hierarchy_kernels():
-    """mpe_residency_plan: everything cached while the state rows fit ~200 MiB of the 256 MiB Infinity Cache; beyond,
-    agent positions keep their place, then velocities, then landmarks; leader_force rows never claim space."""
+    """mpe_residency_plan: everything cached while the rows a step touches fit 250 MiB of the 256 MiB Infinity Cache; beyond,
+    the write-only rows go first (comm, then leader_force), then the read-only landmarks, then the velocities."""
     from marl_amd import _hip
     from tests.gpu_util_host import desc_from_spec
     gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
     ten = desc_from_spec(O.hier_spec_from_golden(np.load(os.path.join(gd, 'h_S1L2F2_10Targets_wide.npz'))))
     mov = desc_from_spec(O.hier_spec_from_golden(np.load(os.path.join(gd, 'm_S1L2F4_MovingTarget.npz'))))
     plan = _hip.lib.mpe_residency_plan
-    LM, VEL, LF = 1, 2, 4
+    LM, VEL, LF, COMM = 1, 2, 4, 8
     ld = 1048576 + 128
     assert plan(ten, 65536, 8) == 0 and plan(ten, ld // 2, 4) == 0
-    assert plan(ten, ld // 2, 8) == 0 == plan(ten, ld, 4)                    # 5 + 10 entities: 168 MB of state + 42 MB of leader_force fit
-    assert plan(ten, ld, 8) == LM | LF == plan(ten, 2 * ld, 4)               # f64 1 Mi: 84 + 84 MB cached, 168 MB of targets streamed
-    assert plan(ten, 2 * ld, 8) == LM | VEL | LF and plan(ten, 4 * ld, 8) == LM | LF   # velocities: only while the positions still fit
-    assert plan(mov, ld, 4) == 0 and plan(mov, ld, 8) == LF                  # 8 agents, no landmarks: 268 MB of positions + velocities stay
-    assert plan(mov, 2 * ld, 8) == VEL | LF and plan(mov, 4 * ld, 8) == LF
+    # 5 + 10 entities at 1 Mi f32: 168 MB of state + 42 MB of leader_force fit, the 21 comm rows (88 MB) on top do not
+    assert plan(ten, ld // 2, 8) == COMM == plan(ten, ld, 4)
+    assert plan(ten, ld, 8) == LM | LF | COMM == plan(ten, 2 * ld, 4)        # f64 1 Mi: 84 + 84 MB cached, 168 MB of targets streamed
+    assert plan(ten, 2 * ld, 8) == LM | VEL | LF | COMM                      # velocities: only while the positions still fit
+    assert plan(ten, 4 * ld, 8) == LM | LF | COMM
+    assert plan(mov, ld // 2, 4) == 0 and plan(mov, ld, 4) == COMM           # 8 agents, no landmarks
+    assert plan(mov, ld, 8) == LF | COMM                                     # 268 MB of positions + velocities stay
+    assert plan(mov, 2 * ld, 8) == VEL | LF | COMM and plan(mov, 4 * ld, 8) == LF | COMM
     assert plan(ten, 0, 8) < 0 and plan(ten, ld, 2) < 0
