@@ -767,9 +767,11 @@ __device__ __forceinline__ T tag_bound_sel(T x) {
 // The NT nearest visible targets of one observer as a list sorted by (d2, index), kept while the targets stream by in
 // index order (L1F2_3Targets_100observe.py:242-245: a stable sort of the visible targets by squared distance).  Slots
 // start at (+inf, -1); an invisible target enters as +inf and stops in front of nothing.  One candidate bubbles
-// through the list: the strict comparison leaves an equal, earlier-index entry in front, like the stable sort; the
-// distances move with v_min / v_max, only the indices need selects (13 vector instructions for NT = 3, no branches:
-// the select form of the same insertion compiled to three exec-mask regions per target).
+// through the list: the strict comparison leaves an equal, earlier-index entry in front, like the stable sort, and
+// from the slot it takes onwards the list shifts by one (the entry pushed out is an earlier index than an equal
+// successor: comparing it again would let the successor pass it -- found by the f32 kernel-form fuzz on an exact tie of
+// two targets behind a nearer third).  The distances move with v_min / v_max, only the indices need selects (no
+// branches: the select form of the same insertion compiled to three exec-mask regions per target).
 template <typename T> __device__ __forceinline__ T t_min(T a, T b);
 template <> __device__ __forceinline__ float t_min<float>(float a, float b) { return __builtin_fminf(a, b); }
 template <> __device__ __forceinline__ double t_min<double>(double a, double b) { return __builtin_fmin(a, b); }
@@ -788,9 +790,11 @@ template <typename T, int NT>
 __device__ __forceinline__ void nearest_insert(T (&bd)[NT], int (&bl)[NT], T d2, bool seen, int l) {
   T x = seen ? d2 : T(INFINITY);  // (a NaN d2 is not seen: NaN < r2 is false)
   int xi = l;
+  bool placed = false;  // once the candidate is in, x is the entry it pushed out: that one goes in front of an equal successor
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const bool front = x < bd[k];
+    const bool front = placed || x < bd[k];
+    placed = front;
     const T lo = t_min<T>(bd[k], x), hi = t_max<T>(bd[k], x);
     const int li = front ? xi : bl[k], hi_i = front ? bl[k] : xi;
     bd[k] = lo;

@@ -352,6 +352,36 @@ def test_residency_variants_bit_identical(golden_dir, base, dtype):
             assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('base', ['S1L2F2_10Targets_wide', 'S1L2F2_3Targets_100observe', 'L1F2_3Targets_075observe',
+                                  'L1F1_10Targets_wide'])
+def test_equidistant_targets_keep_their_index_order(golden_dir, base, dtype, force_tile):
+    """The visible targets are listed nearest first by a STABLE sort (L1F2_3Targets_100observe.py:242-245): targets at
+    exactly the same squared distance stay in index order.  Entities on a grid of eighths: every distance is exact in
+    f32 and ties are everywhere, also behind a nearer target that arrives later (the case the sorted-list insertion
+    of the register kernels got wrong until the f32 kernel-form fuzz met one).  Observations and counters exact."""
+    spec = _spec_of(golden_dir, base)
+    spec = dataclasses.replace(spec, obs_r=[0.75, 0.5, 0.625, 0.75, 1.0][:spec.n_agents])   # (exact squares; wide enough to see a few targets)
+    A, E, B = spec.n_agents, spec.n_entities, 4096 + 37
+    rng = np.random.RandomState(77)
+    pos = rng.randint(-5, 6, (E, 2, B)) / 8.0
+    pos[A:, :, : B // 2] = rng.randint(-2, 3, (E - A, 2, B // 2)) / 8.0    # a tight cluster of targets: many equal distances
+    vel = rng.randint(-4, 5, (A, 2, B)) / 8.0
+    lf0 = rng.randint(-8, 9, (A, 2, B)) / 8.0
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    obs, _, info = O.BatchedOracle(spec, npdt).observe(pos, vel, lforce=lf0)
+    d2 = ((pos[A:, None] - pos[None, :A]) ** 2).sum(2)                      # [L, A, B]
+    ds = np.sort(np.where(d2 < (np.asarray(spec.obs_r) ** 2)[None, :, None], d2, np.inf), 0)[:spec.n_target_obs + 1]
+    ties = ((ds[1:] == ds[:-1]) & np.isfinite(ds[1:])).any(0)             # [A, B]: equal distances among the listed targets
+    assert ties.sum() > B // 4 and ties.any(1).all()
+    sim = HipSim(spec, B, dtype)
+    sim.set_state(pos, vel, lforce=lf0)
+    sim.observe()
+    got = sim.host()
+    assert np.array_equal(got[2], np.concatenate(obs, 0).astype(npdt))
+    assert np.array_equal(got[4], np.asarray(info).reshape(got[4].shape))
+
+
 @pytest.mark.parametrize('base', MOVING)
 def test_moving_world_in_which_nobody_is_commanded(golden_dir, base, force_tile):
     """forced_id = -1 everywhere: no agent has a leader_force (the world keeps no such rows at all), yet the observations

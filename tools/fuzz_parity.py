@@ -326,6 +326,45 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
                     print('F32 MISMATCH world %d (%s A=%d L=%d) %s: max err %.3e   spec=%r'
                           % (w, kind, A, spec.n_landmarks, nm, np.nanmax(np.abs(x - np.asarray(y).reshape(x.shape))), spec), flush=True)
                     break
+        # f32 again, free-running: every kernel form steps the world T times from the same state and actions; the forms
+        # keep one operation order, so all outputs agree bit for bit (the f64 leg pins that order to the oracle)
+        if not perturb:
+            forms = (0, 1, 2) if kind in ('stock_hier', 'stock_small') else (0, 1)
+            sims = []
+            for flags in forms:
+                sim = HipSim(spec, B, torch.float32)
+                sim.set_state(pos, vel, goal, lf0)
+                if lm_moves:
+                    sim.lvel.copy_(dev(lvel0, torch.float32))
+                sims.append(sim)
+            names = ('pos', 'vel', 'obs', 'rew', 'info') + (('lvel',) if lm_moves else ()) + (('lforce',) if lf0 is not None else ())
+            differ = False
+            for t in range(T):
+                outs = []
+                for flags, sim in zip(forms, sims):
+                    set_call_flags(flags)
+                    try:
+                        sim.env_step(dev(acts[t], torch.float32), dev(noises[t], torch.float32) if has_noise else None)
+                    finally:
+                        set_call_flags(0)
+                    outs.append(sim.host() + ((sim.lvel.cpu().numpy(),) if lm_moves else ())
+                                + ((sim.lforce[..., :B].cpu().numpy(),) if lf0 is not None else ()))
+                for flags, other in zip(forms[1:], outs[1:]):
+                    for nm, x, y in zip(names, outs[0], other):
+                        if not np.array_equal(x, y, equal_nan=True):
+                            bad += 1
+                            differ = True
+                            x2, y2 = x.reshape(-1, B), y.reshape(-1, B)
+                            ne = ~((x2 == y2) | (np.isnan(x2) & np.isnan(y2)))
+                            rows = np.nonzero(ne.any(1))[0]
+                            r0 = rows[0]
+                            e0 = np.nonzero(ne[r0])[0][0]
+                            print('F32 KERNEL FORMS DIFFER world %d (%s A=%d L=%d) step %d flags=%d vs %d %s: rows %s, %d envs; row %d env %d: %r vs %r   spec=%r'
+                                  % (w, kind, A, spec.n_landmarks, t, forms[0], flags, nm, rows.tolist(), int(ne.any(0).sum()), r0, e0,
+                                     float(x2[r0, e0]), float(y2[r0, e0]), spec), flush=True)
+                            break
+                if differ:
+                    break
         kernels[kind] = kernels.get(kind, 0) + 1
         if progress and (w + 1) % progress == 0:
             print('... %d worlds, %d mismatching runs so far' % (w + 1, bad), flush=True)
