@@ -929,6 +929,15 @@ class SerialEnv:
 # --------------------------------------------------------------------------------------
 # Batched restatement (SoA, vectorised over envs, same per-element operation order)
 # --------------------------------------------------------------------------------------
+def _pymin(m, x):
+    """One step of Python's min() over a sequence, vectorised: the running minimum is replaced only where `x < m`, so
+    a NaN that comes FIRST stays and a later NaN is passed over (np.minimum would spread either; the scenario files call
+    the builtin: simple_spread.py:74, simple_adversary.py:96, simple_world_comm.py:163,203).  Such states exist: two
+    coincident colliding entities get a NaN force (core.py:239-243) and keep NaN positions to the end of the episode."""
+    with np.errstate(invalid='ignore'):
+        return np.where(x < m, x, m)
+
+
 def _norm2_blas(d0, d1):
     """np.linalg.norm of a 2-vector as the reference computes it (core.py:185,188): sqrt(dot(x, x)), and
     this container's BLAS dot rounds as fma(x1, x1, x0*x0) (checked against np.linalg.norm on 20 000
@@ -1335,7 +1344,7 @@ class BatchedOracle:
                     adv_rew = adv_rew + np.sqrt(sq(pos[a], gp))
                 m = np.sqrt(sq(pos[goods[0]], gp))
                 for g in goods[1:]:
-                    m = np.minimum(m, np.sqrt(sq(pos[g], gp)))
+                    m = _pymin(m, np.sqrt(sq(pos[g], gp)))
                 for i in range(A):
                     if s.adversary[i]:
                         rew[i] = -sq(pos[i], gp)
@@ -1348,7 +1357,7 @@ class BatchedOracle:
             else:
                 m = np.sqrt(sq(pos[goods[0]], gp))
                 for g in goods[1:]:
-                    m = np.minimum(m, np.sqrt(sq(pos[g], gp)))
+                    m = _pymin(m, np.sqrt(sq(pos[g], gp)))
                 for i in range(A):
                     if s.adversary[i]:
                         rew[i] = m - np.sqrt(sq(gp, pos[i]))
@@ -1395,7 +1404,7 @@ class BatchedOracle:
             for i in advs:
                 m = self._dist(pos, goods[0], i)
                 for g in goods[1:]:
-                    m = np.minimum(m, self._dist(pos, g, i))
+                    m = _pymin(m, self._dist(pos, g, i))
                 r = T(0) - T(0.1) * m
                 if s.collide[i]:
                     for g in goods:
@@ -1419,7 +1428,7 @@ class BatchedOracle:
                     r = r + T(2) * touch(i, f)
                 m = self._dist(pos, food[0], i)
                 for f in food[1:]:
-                    m = np.minimum(m, self._dist(pos, f, i))
+                    m = _pymin(m, self._dist(pos, f, i))
                 rew[i] = r + T(0.05) * m
         return obs, rew, info
 
@@ -1488,7 +1497,7 @@ class BatchedOracle:
                 for l in range(L):
                     m = self._dist(pos, 0, A + l)
                     for a in range(1, A):
-                        m = np.minimum(m, self._dist(pos, a, A + l))
+                        m = _pymin(m, self._dist(pos, a, A + l))
                     md = md + m
                     r0 = r0 - m
                     occ = occ + (m < T(0.1))

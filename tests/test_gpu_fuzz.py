@@ -34,6 +34,21 @@ def test_stock_shapes_with_random_constants_match_the_oracle():
     assert bad == 0 and refused == 0 and set(kinds) == {'stock_hier', 'stock_small'} and min(kinds.values()) >= 100
 
 
+@pytest.mark.parametrize('stock', [False, True], ids=['random', 'stock'])
+def test_worlds_on_a_grid_match_the_oracle(stock):
+    """The same worlds with every entity on a grid and sizes / radii on the same grid: centre distances exactly AT the contact
+    and visibility thresholds (strict comparisons on both sides), exact ties in the nearest-target order (stable), and
+    coincident colliding entities, whose NaN force (core.py:239-243) then runs through three steps of physics and gathers:
+    NaN for NaN like the reference (Python min() over a list keeps a leading NaN, skips a later one).  f64 <= 1e-9 vs the
+    oracle incl. the observe-only call on the grid state; f32: all kernel forms agree bit for bit."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_parity.py')
+    spec = importlib.util.spec_from_file_location('fuzz_parity', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, refused, kinds = mod.run(150, 11 + stock, stock_only=stock, grid=True)
+    assert bad == 0 and refused == 0 and min(kinds.values()) >= 5
+
+
 @pytest.mark.parametrize('mk', ['tag', 'spread', 'hier', 'wcomm'])
 def test_batch_size_edges(mk, golden_dir):
     """B = 1, around the wavefront / workgroup / tile sizes and around the small-batch switch (MPE_SPLIT_MAX_ENVS), each in

@@ -2,7 +2,9 @@
 and random per-entity constants (sizes, masses, accel None or a value, max_speed None or a value, collide flags in
 irregular patterns, u_noise on some agents, damping / dt / contact constants), dense starts so that contacts happen.
 f64, every output of 3 steps within 1e-9 (NaN patterns equal).  Run on the GPU box from the repo root:
-    python tools/fuzz_parity.py [n_worlds] [seed] [stock|moving]      (stock: only the shapes that have register kernels; moving: only random *_MovingTarget-like worlds)
+    python tools/fuzz_parity.py [n_worlds] [seed] [stock|moving] [grid]   (stock: only the shapes that have register kernels; moving: only random *_MovingTarget-like worlds;
+    grid: entities start on a grid with sizes and radii on the same grid -- distances EXACTLY at the contact / visibility thresholds, exact ties in the
+    target order, coincident entities whose NaN forces spread)
 Prints one line per mismatch or refusal and a summary; exit status 1 if anything differs."""
 import dataclasses
 import os
@@ -205,7 +207,7 @@ def random_spec(rng, stock_only=False):
     return kind, dataclasses.replace(spec, **rep)
 
 
-def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
+def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0, grid=False):
     """-> (mismatching runs, worlds refused by mpe_desc_check, worlds per kind).  perturb != 0: the oracle steps a world
     whose damping differs by that much (negative control: the comparison must notice)."""
     rng = np.random.RandomState(seed)
@@ -229,6 +231,17 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
             assert on_tile or rows == [-(-B // (64 if splits else 256)), -(-B // 256)], (rows, spec)
         pos = rng.uniform(-0.45, 0.45, (E, 2, B))
         vel = rng.uniform(-0.8, 0.8, (A, 2, B))
+        if grid:   # cells of 1/8 (1/32 in a crowded world); sizes in half cells, so that centre distances hit size sums exactly
+            cell = 0.125 if E <= 12 else 0.03125
+            n = int(round(0.5 / cell))
+            pos = rng.randint(-n, n + 1, (E, 2, B)) * cell
+            vel = rng.randint(-6, 7, (A, 2, B)) * 0.125
+            rep = dict(size=[float(rng.randint(1, 4)) * cell / 2 for _ in range(E)])
+            if spec.obs_r is not None:
+                rep['obs_r'] = [float(rng.randint(1, 9)) * cell if r else r for r in spec.obs_r]
+            spec = dataclasses.replace(spec, **rep)
+            d = desc_from_spec_or_none(spec)
+            assert d is not None
         lm_moves = any(spec.movable[A:])
         lvel0 = rng.uniform(-0.8, 0.8, (E - A, 2, B)) * np.asarray(spec.movable[A:], float)[:, None, None] if lm_moves else None
         gr = spec.goal_rows                  # per-env goal landmark(s): one row, or one per agent (simple_reference)
@@ -238,6 +251,8 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
         hier = spec.kind in (O.HIER_PURSUIT, O.HIER_MOVING)
         ragged = hier or not all(spec.silent)
         lf0 = rng.uniform(-1, 1, (A, 2, B)) if hier and spec.has_leader_force else None
+        if lf0 is not None:   # nobody writes the leader_force of an agent no leader commands: it keeps make_world's zeros
+            lf0 = lf0 * (np.asarray(spec.forced_id) >= 0)[:, None, None]
         acts = [rng.rand(sum(spec.act_dims), B) if ragged else rng.dirichlet(np.ones(5), (A, B)).transpose(0, 2, 1)
                 for _ in range(T)]
         noises = [rng.randn(A, 2, B) for _ in range(T)]
@@ -253,6 +268,20 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
                 if lm_moves:
                     sim.lvel.copy_(dev(lvel0, torch.float64))
                 p, v, lv = pos, vel, lvel0
+                if grid:   # the gathers ON the grid state (a step leaves it): thresholds met exactly, ties in the target order
+                    comm0 = np.zeros((A, spec.dim_c, B)) if spec.dim_c else None
+                    wobs, wrew, winfo = bo.observe(pos, vel, goal=goal_arg, lforce=lf0, comm=comm0)
+                    sim.observe(comm=dev(comm0, torch.float64) if spec.dim_c else None)
+                    for nm, x, y in zip(('obs', 'rew', 'info'), sim.host()[2:], (np.concatenate(wobs, 0), wrew, winfo)):
+                        if y is None or x.size == 0:
+                            continue
+                        y = np.asarray(y, np.float64).reshape(x.shape)
+                        if not (np.array_equal(np.isnan(x), np.isnan(y)) and np.nanmax(np.abs(x - y), initial=0.0) <= 1e-9):
+                            bad += 1
+                            ne = ~(np.isclose(x, y, rtol=0, atol=1e-9) | (np.isnan(x) & np.isnan(y))).reshape(-1, B)
+                            print('GRID OBSERVE MISMATCH world %d (%s A=%d L=%d) flags=%d %s: rows %s, %d envs   spec=%r'
+                                  % (w, kind, A, spec.n_landmarks, flags, nm, np.nonzero(ne.any(1))[0].tolist(), int(ne.any(0).sum()), spec), flush=True)
+                            raise StopIteration
                 for t in range(T):
                     sim.env_step(dev(acts[t], torch.float64), dev(noises[t], torch.float64) if has_noise else None)
                     res = bo.env_step(p, v, acts[t], noises[t] if has_noise else None,
@@ -374,7 +403,8 @@ def run(n_worlds, seed, perturb=0.0, stock_only=False, progress=0):
 def main():
     n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, refused, kinds = run(n_worlds, seed, stock_only=(sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] == 'moving' else len(sys.argv) > 3 and sys.argv[3] == 'stock'), progress=500)
+    mode = sys.argv[3:]
+    bad, refused, kinds = run(n_worlds, seed, stock_only=('moving' if 'moving' in mode else 'stock' in mode), progress=500, grid='grid' in mode)
     print('worlds %d (refused by mpe_desc_check: %d), by kind %s, mismatching (world, kernel) runs: %d'
           % (n_worlds, refused, kinds, bad))
     sys.exit(1 if bad else 0)
