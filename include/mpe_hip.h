@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define MPE_ABI_VERSION 11
+#define MPE_ABI_VERSION 12
 #define MPE_MAX_AGENTS 64
 #define MPE_MAX_ENTITIES 128
 
@@ -451,6 +451,36 @@ int mpe_replay_gather_compact_f32(int64_t capacity, int od, int ad, int64_t n, c
                                   const void *ring, const void *ends, const uint8_t *own, void *out, void *stream);
 int mpe_replay_gather_compact_f64(int64_t capacity, int od, int ad, int64_t n, const int64_t *idx, int64_t batch,
                                   const void *ring, const void *ends, const uint8_t *own, void *out, void *stream);
+
+/*
+ * STEP STORE: replay without an append.  The step kernels already write everything a transition holds -- the actors
+ * the action rows, mpe_env_step the reward rows and the NEXT observation rows -- so a caller that hands them a different
+ * slot of
+ *     obs  [slots][obs_rows][ld]    rew  [slots][rew_rows][ld]
+ *     act  [slots][act_rows][ld]    done [slots][rew_rows][ld]  (or NULL: every done is 0, environment.py:108 without a
+ *                                                                 done_callback)
+ * at every step has its replay ring for free: transition (slot s, env e) is obs[s] | act[s] | rew[s] | obs[(s + 1) %
+ * slots] | done[s].  A slot that only holds the last observation of an episode (the reset writes into the next one) has
+ * no transition of its own; `live` (device, int32 [slots + 1]) lists the slots that do, oldest first, in its first
+ * n_live entries and holds n_live once more in entry [slots] -- the kernel reads the count THERE, so that a gather
+ * recorded in a HIP graph follows a store that grows between replays; the struct's n_live is the host's copy, used for
+ * the argument checks.  Transition index i addresses env i % n of slot live[i / n] (indices outside [0, n_live n) wrap).  mpe_replay_gather_steps returns the rows of ONE agent
+ * (its observation rows obs_row0 .. + od, action rows act_row0 .. + ad, reward row rew_row) in the full layout of
+ * mpe_replay_gather, out [batch][2 od + ad + 2]: the same bytes as a full ring fed the same transitions
+ * (tests/test_gpu_replay.py).  No counterpart in the reference (replay_buffer.py:25-32 appends Python tuples); host side:
+ * marl_amd.replay_buffer.StepStore.
+ */
+typedef struct mpe_step_store {
+  const void *obs, *act, *rew, *done;                  /* done may be NULL */
+  const int32_t *live;                                 /* device, [slots + 1]: table, then the count */
+  int64_t obs_slot_stride, act_slot_stride, rew_slot_stride; /* elements between consecutive slots */
+  int64_t ld, n;                                       /* row stride; envs (transitions) per slot */
+  int32_t slots, n_live, obs_row0, act_row0, rew_row, pad_;
+} mpe_step_store;
+int mpe_replay_gather_steps_f32(const mpe_step_store *store, int od, int ad, const int64_t *idx, int64_t batch, void *out,
+                                void *stream);
+int mpe_replay_gather_steps_f64(const mpe_step_store *store, int od, int ad, const int64_t *idx, int64_t batch, void *out,
+                                void *stream);
 
 /*
  * Actor forward of the learner for every env in one launch (maddpg/maddpg/trainer/maddpg.py:39-45,151-152;

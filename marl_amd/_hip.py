@@ -26,7 +26,7 @@ MPE_SIMPLE_CRYPTO = 8
 MPE_WORLD_COMM = 9
 MPE_HIER_MOVING = 10
 GOAL_KINDS = (MPE_SIMPLE_ADVERSARY, MPE_SIMPLE_PUSH, MPE_SPEAKER_LISTENER, MPE_SIMPLE_REFERENCE, MPE_SIMPLE_CRYPTO)
-ABI_VERSION = 11
+ABI_VERSION = 12
 FLAG_FORCE_TILE = 1
 FLAG_WIDE = 2          # simple_tag / simple_spread: one env per lane at any batch size
 FLAG_SPLIT = 4         # ... one agent per wavefront (the small-batch form) at any batch size
@@ -101,6 +101,15 @@ class ReplayJob(C.Structure):
                 ('segs', C.POINTER(ReplaySeg)), ('ring', C.c_void_p)]
 
 
+class StepStoreDesc(C.Structure):
+    """mpe_step_store (include/mpe_hip.h): the rows of a step store, seen by one agent's gather."""
+    _fields_ = [('obs', C.c_void_p), ('act', C.c_void_p), ('rew', C.c_void_p), ('done', C.c_void_p), ('live', C.c_void_p),
+                ('obs_slot_stride', C.c_int64), ('act_slot_stride', C.c_int64), ('rew_slot_stride', C.c_int64),
+                ('ld', C.c_int64), ('n', C.c_int64),
+                ('slots', C.c_int32), ('n_live', C.c_int32), ('obs_row0', C.c_int32), ('act_row0', C.c_int32),
+                ('rew_row', C.c_int32), ('pad_', C.c_int32)]
+
+
 class ActorJob(C.Structure):
     """mpe_actor_job (include/mpe_hip.h): one agent's share of a multi-agent actor launch."""
     _fields_ = [('obs', C.c_void_p), ('weights', C.c_void_p), ('u', C.c_void_p), ('act', C.c_void_p),
@@ -157,6 +166,8 @@ def _load():
         f.restype, f.argtypes = ci, [i64, ci, vp, i64, vp, vp, vp]
         f = getattr(L, 'mpe_replay_gather_compact_' + suf)  # capacity, od, ad, n, idx, batch, ring, ends, own, out, stream
         f.restype, f.argtypes = ci, [i64, ci, ci, i64, vp, i64, vp, vp, vp, vp, vp]
+        f = getattr(L, 'mpe_replay_gather_steps_' + suf)  # store, od, ad, idx, batch, out, stream
+        f.restype, f.argtypes = ci, [C.POINTER(StepStoreDesc), ci, ci, vp, i64, vp, vp]
     # B, ld_obs, ld_act, in_dim, s0, s1, obs, weights, u, seed, call_counter, env_id0, act, stream
     L.mpe_actor_forward_f32.restype = ci
     L.mpe_actor_forward_f32.argtypes = [i64, i64, i64, ci, ci, ci, vp, vp, vp, u64, u32, u64, vp, vp]

@@ -1310,6 +1310,75 @@ static int replay_gather_compact_impl(int64_t capacity, int od, int ad, int64_t 
   return (int)hipGetLastError();
 }
 
+// Gather from a STEP STORE (include/mpe_hip.h, mpe_replay_gather_steps): the rows the step kernels wrote, kept where
+// they were written -- per step slot the observation rows [obs_rows][ld], action rows [act_rows][ld], reward rows and
+// (optionally) done rows of all agents.  Transition i = (k = i / n, env = i % n) lives in slot live[k]; its obs_tp1 are
+// the observation rows of slot (live[k] + 1) % slots.  Output rows in the full layout of mpe_replay_gather.
+template <typename T>
+__global__ __launch_bounds__(256) void replay_gather_steps_kernel(mpe_step_store st, int od, int ad, const int64_t *idx,
+                                                                  int64_t total, T *out) {
+  const int width = 2 * od + ad + 2;
+  const T *obs = (const T *)st.obs, *act = (const T *)st.act, *rew = (const T *)st.rew, *done = (const T *)st.done;
+  // the count is read from device memory, behind the table: a gather recorded in a HIP graph bakes its arguments, and
+  // the store grows between replays
+  int n_live = st.live[st.slots];
+  n_live = n_live < 1 ? 1 : (n_live >= st.slots ? st.slots - 1 : n_live);
+  const int64_t cap = (int64_t)n_live * st.n;
+  const int64_t blk = (int64_t)blockIdx.x * 1024;
+  const int64_t b0 = blk / width;
+  const uint32_t off0 = (uint32_t)(blk - b0 * width);
+  const int64_t g0 = blk + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t g = g0 + 256 * u;
+    if (g >= total) continue;
+    const uint32_t t = off0 + threadIdx.x + 256u * u;
+    const uint32_t db = t / (uint32_t)width;
+    const int j = (int)(t - db * (uint32_t)width);
+    int64_t i = idx[b0 + db];
+    if ((uint64_t)i >= (uint64_t)cap) {  // out of range: wrap instead of faulting
+      i %= cap;
+      i = i < 0 ? i + cap : i;
+    }
+    const int64_t k = i / st.n, e = i - k * st.n;
+    int slot = st.live[k];
+    slot = (slot < 0 || slot >= st.slots) ? 0 : slot;
+    T v;
+    if (j < od) {
+      v = obs[(int64_t)slot * st.obs_slot_stride + (int64_t)(st.obs_row0 + j) * st.ld + e];
+    } else if (j < od + ad) {
+      v = act[(int64_t)slot * st.act_slot_stride + (int64_t)(st.act_row0 + j - od) * st.ld + e];
+    } else if (j == od + ad) {
+      v = rew[(int64_t)slot * st.rew_slot_stride + (int64_t)st.rew_row * st.ld + e];
+    } else if (j == width - 1) {
+      v = done != nullptr ? done[(int64_t)slot * st.rew_slot_stride + (int64_t)st.rew_row * st.ld + e] : T(0);
+    } else {
+      const int nx = slot + 1 == st.slots ? 0 : slot + 1;
+      v = obs[(int64_t)nx * st.obs_slot_stride + (int64_t)(st.obs_row0 + j - (od + ad + 1)) * st.ld + e];
+    }
+    out[g] = v;
+  }
+}
+
+template <typename T>
+static int replay_gather_steps_impl(const mpe_step_store *st, int od, int ad, const int64_t *idx, int64_t batch, void *out,
+                                    void *stream) {
+  if (!st || !idx || !out || !st->obs || !st->act || !st->rew || !st->live) return MPE_ERR_NULL;
+  if (st->slots < 2 || st->n_live < 1 || st->n_live >= st->slots || st->n < 1 || st->ld < st->n || od < 1 || ad < 1 ||
+      batch < 0 || st->obs_row0 < 0 || st->act_row0 < 0 || st->rew_row < 0 ||
+      st->obs_slot_stride < (int64_t)(st->obs_row0 + od) * st->ld || st->act_slot_stride < (int64_t)(st->act_row0 + ad) * st->ld ||
+      st->rew_slot_stride < (int64_t)(st->rew_row + 1) * st->ld)
+    return MPE_ERR_ARG;
+  if (misaligned<T>(st->obs) || misaligned<T>(st->act) || misaligned<T>(st->rew) || misaligned<T>(st->done) ||
+      misaligned<T>(out) || misaligned<int64_t>(idx) || misaligned<int32_t>(st->live))
+    return MPE_ERR_ALIGN;
+  if (batch == 0) return MPE_OK;
+  const int64_t total = batch * (2 * od + ad + 2);
+  const dim3 grid((unsigned)((total + 1023) / 1024)), block(256);
+  hipLaunchKernelGGL(replay_gather_steps_kernel<T>, grid, block, 0, (hipStream_t)stream, *st, od, ad, idx, total, (T *)out);
+  return (int)hipGetLastError();
+}
+
 template <typename T>
 static int replay_gather_impl(int64_t capacity, int width, const int64_t *idx, int64_t batch, const void *ring,
                               void *out, void *stream) {
@@ -1544,6 +1613,10 @@ extern "C" int mpe_env_step_stats_static(const mpe_scenario_desc *d, int64_t B, 
                                                  int64_t batch, const void *ring, const void *ends,                  \
                                                  const uint8_t *own, void *out, void *stream) {                      \
     return replay_gather_compact_impl<T>(capacity, od, ad, n, idx, batch, ring, ends, own, out, stream);            \
+  }                                                                                                            \
+  extern "C" int mpe_replay_gather_steps_##SUF(const mpe_step_store *store, int od, int ad, const int64_t *idx,       \
+                                               int64_t batch, void *out, void *stream) {                              \
+    return replay_gather_steps_impl<T>(store, od, ad, idx, batch, out, stream);                                       \
   }                                                                                                            \
   extern "C" int mpe_reset_##SUF(const mpe_scenario_desc *d, int64_t B, int64_t ld, uint64_t seed,             \
                                  uint32_t episode, uint64_t env_id0, const uint8_t *mask,                      \

@@ -197,6 +197,93 @@ class CapturedTrainSteps(object):
         return self.last
 
 
+class CapturedStoreSteps(object):
+    """``CapturedTrainSteps`` for a ``marl_amd.replay_buffer.StepStore``: K iterations of
+
+        action_n = act_all(trainers, obs_n, out=store.action_views())   # every actor: 1 launch, into the slot's rows
+        obs_n, rew_n, done_n, info_n = store.step()                     # fused env step: 1 launch, into the slot's rows
+
+    in one HIP graph -- two launches per iteration, the replay append is gone.  A recorded launch bakes its pointers and
+    every step uses another slot, so there is one graph per window of K + 1 slots (K transitions + the slot of the last
+    obs_tp1; the reset that follows a replay lands in the first slot of the next window): ``store.slots % (K + 1) == 0``,
+    graphs are recorded the first time their window comes up.  ``store.align(K + 1)`` moves a store that is between
+    windows to the next one."""
+
+    def __init__(self, env, trainers, store, K, kernel=0):
+        if store.env is not env:
+            raise ValueError('the store belongs to another env')
+        self.env, self.trainers, self.store, self.K, self.kernel = env, list(trainers), store, int(K), kernel
+        if store.slots % (self.K + 1) != 0:
+            raise ValueError('CapturedStoreSteps: %d slots are not a multiple of K + 1 = %d' % (store.slots, self.K + 1))
+        if any(tr._packed is None for tr in self.trainers):
+            raise RuntimeError('run one eager act_all before capturing (the packed actor weights must exist)')
+        self.ctr = torch.zeros(1, dtype=torch.int32, device=env.world.device)
+        self._windows = {}
+
+    def _capture(self, s0):
+        from .maddpg import act_all
+        env, w, st = self.env, self.env.world, self.store
+        base_calls = self.trainers[0]._act_calls
+        noise_base = (w.noise_step - w._noise_dev_val) & 0xFFFFFFFF
+        host = ([tr._act_calls for tr in self.trainers], (w._tick, w._obs_tick, w._gather_tick, w.act, w.noise_step, w.rew))
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(w.device)
+        try:
+            with _hip.on_device(w.device):
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    obs_n = [w.obs_views[i] for i in env._pidx]
+                    for k in range(self.K):
+                        s = s0 + k
+                        act_all(self.trainers, obs_n, out=st._act_views[s], kernel=self.kernel, counter_dev=self.ctr)
+                        w.rew = st.rew[s]
+                        w._buf.set(rew=w.rew)
+                        obs_n, rew_n, done_n, info_n = env.step(st._act_soa[s])
+                    last = (obs_n, rew_n, done_n, info_n)
+        finally:
+            for tr, c in zip(self.trainers, host[0]):
+                tr._act_calls = c
+            w._tick, w._obs_tick, w._gather_tick, w.act, w.noise_step, w.rew = host[1]
+            w._buf.set(rew=w.rew)
+            st._set_slot(s0)
+        return graph, last, base_calls, noise_base
+
+    def replay(self):
+        """Runs the K iterations from the current slot; returns the last one's ``(obs_n, reward_n, done_n, info_n)``."""
+        env, w, st, K = self.env, self.env.world, self.store, self.K
+        if w._obs_tick != w._tick:
+            raise RuntimeError('replay right after env.reset() or a step: the observations must be current')
+        s0 = st._sync()
+        if s0 % (K + 1) != 0:
+            raise RuntimeError('CapturedStoreSteps.replay: the store is at slot %d, not at the start of a window of %d '
+                               '(store.align(%d) moves it there)' % (s0, K + 1, K + 1))
+        if s0 not in self._windows:
+            self._windows[s0] = self._capture(s0)
+        graph, last, base_calls, noise_base = self._windows[s0]
+        delta = (self.trainers[0]._act_calls - base_calls) & 0xFFFFFFFF
+        self.ctr.fill_(delta - (1 << 32) if delta >= (1 << 31) else delta)
+        w._clean_silent_comm()
+        if w._buf.flags & _hip.FLAG_DEVICE_NOISE:
+            w._set_noise_dev(w.noise_step - noise_base)
+        graph.replay()
+        w.noise_step = (w.noise_step + K) & 0xFFFFFFFF
+        for tr in self.trainers:
+            tr._act_calls += K
+        for k in range(K + 1):                     # K new transitions; the slot behind them holds the last obs_tp1
+            st._drop(s0 + k)
+        st._live.extend(range(s0, s0 + K))
+        st._live_dirty = True
+        st._set_slot(s0 + K)
+        st._cursor = s0 + K
+        w.act = st._act_soa[s0 + K - 1]
+        w.rew = st.rew[s0 + K - 1]
+        w._buf.set(rew=w.rew)
+        w._tick += K
+        w._obs_tick = w._tick
+        if env.info_callback is not None:
+            w._gather_tick = w._tick
+        return last
+
+
 class CapturedUpdates(object):
     """The learners' updates -- ``for tr in trainers: tr.update(trainers, t)`` at a step where an update is due
     (maddpg.py:161-196, experiments/simple_train.py:295-299) -- as ONE HIP-graph replay.

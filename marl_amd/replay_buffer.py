@@ -241,3 +241,213 @@ def add_all(buffers, obs_n, action_n, reward_n, obs_tp1_n, done_n, cursors=False
             _hip.check(fn(len(flat), jobs, n, _hip.stream_of(b0.device)), 'mpe_replay_add_multi')
     for b, p in zip(buffers, prep):
         b._advance(n, p[2], terminal, flags=not cursors)
+
+
+class StepStore(object):
+    """Replay without an append (libmpe_hip.so: mpe_replay_gather_steps_*; include/mpe_hip.h, STEP STORE).
+
+    Everything a transition holds is already written by the step's own launches -- the actors write the action rows,
+    the fused env step the reward rows and the NEXT observation rows -- so the store hands them a different slot of its
+    ``[slots, rows, num_envs]`` arrays at every step and the rings fill themselves: no copy, no append launch (the append
+    was 0.138 ms of the 0.58 ms training step at 1 Mi envs, and 0.217 ms with full records).  Transition (slot s, env e)
+    is ``obs[s] | act[s] | rew[s] | obs[s + 1] | done[s]``; a reset writes its observation into the slot after the
+    episode's last ``obs_tp1``, which therefore holds no transition of its own (one slot per episode).
+
+        store = StepStore(env, slots=104)
+        for tr, view in zip(trainers, store.views()):
+            tr.replay_buffer = view                     # the reference's per-agent buffer interface, read side
+        obs_n = env.reset()
+        while True:
+            action_n = act_all(trainers, obs_n, out=store.action_views())   # or any other writer of those views
+            obs_n, rew_n, done_n, info_n = store.step()                    # env.step on the slot's own action rows
+            if terminal: obs_n = env.reset()
+
+    ``store.step(action_n)`` copies a caller's action list into the slot first.  ``len(view)`` counts the stored
+    transitions; index ``k * num_envs + e`` is env e of the k-th OLDEST stored step (the reference's ring enumerates
+    storage positions instead: the same set, sampled uniformly either way; before the first wrap the two orders
+    coincide).  Samples are bit-identical to a full ``ReplayBuffer`` fed the same steps (tests/test_gpu_replay.py).
+    Needs the fused env step (built-in scenario callbacks), the default action decode and no ``done_callback``."""
+
+    def __init__(self, env, slots):
+        w = env.world
+        if not env._fused or not env._all_policy:
+            raise RuntimeError('StepStore needs the fused env step and no scripted agents')
+        if env.discrete_action_input or not env.discrete_action_space or env.force_discrete_action:
+            raise RuntimeError('StepStore: the stored action rows are the ones the default decode reads')
+        if env.shared_reward:
+            raise RuntimeError('StepStore: shared_reward sums the reward rows on the host side (environment.py:113-115)')
+        S = int(slots)
+        if S < 3:
+            raise ValueError('StepStore needs at least 3 slots')
+        self.env, self.slots = env, S
+        if w.obs is None:
+            w._alloc_outputs()
+        d = w.descriptor()
+        A = len(w.agents)
+        self.obs = w.rows(S, w.obs.shape[0])
+        self.act = w.rows(S, sum(w.act_dims))
+        self.rew = w.rows(S, A)
+        cur = w._obs_slot
+        self.obs[0].copy_(w._obs_pair[cur])         # whatever observations are current stay current, in slot 0
+        w._obs_pair, w._views_pair = [], []
+        for s in range(S):
+            obs = self.obs[s]
+            w._obs_pair.append(obs)
+            w._views_pair.append([obs[_hip.lib.mpe_obs_row0(d, i):_hip.lib.mpe_obs_row0(d, i) + _hip.lib.mpe_obs_dim(d, i)].t()
+                                  for i in range(A)])
+        w._obs_slot = 0
+        w.obs, w.obs_views = w._obs_pair[0], w._views_pair[0]
+        w._buf.set(obs=w.obs)
+        self._act_soa = [self.act[s].view(A, 5, w.num_envs) if w._uniform_actions else self.act[s] for s in range(S)]
+        self._act_views = [[self.act[s][w.act_row0[i]:w.act_row0[i] + w.act_dims[i]].t() for i in env._pidx]
+                           for s in range(S)]
+        self._live = []              # slots that hold a transition, oldest first
+        self._live_dev = torch.zeros(S + 1, dtype=torch.int32, device=w.device)   # the table, then the count
+        self._live_dirty = True
+        self._cursor = 0             # the observation slot after this store's last step
+        self._views = [StepStoreView(self, j) for j in range(env.n)]
+
+    def views(self):
+        return list(self._views)
+
+    def _sync(self):
+        """Observation slots written behind the store's back (a reset, a gather) hold no transition any more."""
+        w = self.env.world
+        s = w._obs_slot
+        j = self._cursor
+        while j != s:
+            j = (j + 1) % self.slots
+            self._drop(j)
+        self._cursor = s
+        return s
+
+    def _drop(self, slot):
+        if slot in self._live:
+            self._live.remove(slot)
+            self._live_dirty = True
+
+    def action_views(self):
+        """``[num_envs, act_dim]`` views of the current slot's action rows, one per policy agent: where the actors write."""
+        return self._act_views[self._sync()]
+
+    def step(self, action_n=None):
+        """``env.step`` with this slot's action rows (``action_n``: copied into them first), rewards into this slot's
+        reward rows, the next observations into the next slot."""
+        env, w = self.env, self.env.world
+        if w._obs_tick != w._tick:
+            raise RuntimeError('StepStore.step: call right after env.reset() or a step (the observations must be current)')
+        s = self._sync()
+        self._drop(s)
+        if action_n is not None:
+            for v, a in zip(self._act_views[s], action_n):
+                if not (torch.is_tensor(a) and a.data_ptr() == v.data_ptr() and a.stride() == v.stride()):
+                    v.copy_(torch.as_tensor(a, dtype=v.dtype, device=v.device).expand(v.shape))
+        w.rew = self.rew[s]
+        w._buf.set(rew=w.rew)
+        out = env.step(self._act_soa[s])
+        q = w._obs_slot                 # holds obs_tp1 now: whatever transition started there is gone
+        self._drop(q)
+        self._live.append(s)
+        self._live_dirty = True
+        self._cursor = q
+        return out
+
+    def _set_slot(self, slot):
+        w = self.env.world
+        w._obs_slot = slot
+        w.obs, w.obs_views = w._obs_pair[slot], w._views_pair[slot]
+        w._buf.set(obs=w.obs)
+
+    def align(self, period):
+        """Moves the current observations to the next slot that is a multiple of ``period`` (slots in between hold no
+        transition afterwards): marl_amd.graph.CapturedStoreSteps records one HIP graph per window of K + 1 slots and
+        starts every episode at such a slot."""
+        s = self._sync()
+        t = (-(-s // period) * period) % self.slots
+        if t != s:
+            self.obs[t].copy_(self.obs[s])
+            j = s
+            while j != t:
+                j = (j + 1) % self.slots
+                self._drop(j)
+            self._set_slot(t)
+            self._cursor = t
+        return t
+
+    def _live_table(self):
+        self._sync()
+        if self._live_dirty:
+            t = torch.tensor(self._live + [0] * (self.slots - len(self._live)) + [len(self._live)], dtype=torch.int32)
+            self._live_dev.copy_(t)
+            self._live_dirty = False
+        return len(self._live)
+
+
+class StepStoreView(object):
+    """One agent's transitions of a ``StepStore`` behind the read side of the reference's ReplayBuffer interface
+    (replay_buffer.py:18-19,46-86); ``add`` raises: the store is filled by the steps themselves."""
+    compact = False
+
+    def __init__(self, store, j):
+        w = store.env.world
+        i = store.env._pidx[j]
+        d = w.descriptor()
+        self.store, self.device, self.dtype = store, w.device, w.dtype
+        self._dims = (_hip.lib.mpe_obs_dim(d, i), w.act_dims[i])
+        self._rows = (_hip.lib.mpe_obs_row0(d, i), w.act_row0[i], i)
+        self.check_index = True
+
+    def __len__(self):
+        return self.store._live_table() * self.store.env.num_envs
+
+    def add(self, *args, **kw):
+        raise RuntimeError('a StepStore view is filled by StepStore.step(), not by add()')
+
+    def clear(self):
+        self.store._live = []
+        self.store._live_dirty = True
+
+    def make_index(self, batch_size):
+        return torch.randint(0, len(self), (batch_size,), device=self.device, dtype=torch.int64)
+
+    def make_latest_index(self, batch_size):
+        n = len(self)
+        if batch_size > n:
+            raise IndexError('make_latest_index(%d) with only %d transitions stored' % (batch_size, n))
+        idx = n - 1 - torch.arange(batch_size, device=self.device, dtype=torch.int64)
+        return idx[torch.randperm(batch_size, device=self.device)]
+
+    def sample_index(self, idxes):
+        st, w = self.store, self.store.env.world
+        n_live = st._live_table()
+        if n_live == 0:
+            raise IndexError('sample from an empty replay buffer')
+        if not torch.is_tensor(idxes):
+            idxes = torch.as_tensor(list(idxes), dtype=torch.int64)
+        idxes = idxes.to(device=self.device, dtype=torch.int64).contiguous()
+        b = idxes.numel()
+        if self.check_index and b:
+            lo, hi = torch.aminmax(idxes)
+            if int(lo) < 0 or int(hi) >= n_live * w.num_envs:
+                raise IndexError('replay index out of range [0, %d): min %d, max %d' % (n_live * w.num_envs, int(lo), int(hi)))
+        od, ad = self._dims
+        out = torch.empty(b, 2 * od + ad + 2, dtype=self.dtype, device=self.device)
+        desc = _hip.StepStoreDesc(obs=st.obs.data_ptr(), act=st.act.data_ptr(), rew=st.rew.data_ptr(), done=None,
+                                  live=st._live_dev.data_ptr(), obs_slot_stride=st.obs.stride(0),
+                                  act_slot_stride=st.act.stride(0), rew_slot_stride=st.rew.stride(0), ld=w.ld,
+                                  n=w.num_envs, slots=st.slots, n_live=n_live, obs_row0=self._rows[0],
+                                  act_row0=self._rows[1], rew_row=self._rows[2])
+        fn = getattr(_hip.lib, 'mpe_replay_gather_steps_' + _hip.suffix(self.dtype))
+        with _hip.on_device(self.device):
+            _hip.check(fn(C.byref(desc), od, ad, idxes.data_ptr(), b, out.data_ptr(), _hip.stream_of(self.device)),
+                       'mpe_replay_gather_steps')
+        return (out[:, :od], out[:, od:od + ad], out[:, od + ad], out[:, od + ad + 1:2 * od + ad + 1],
+                out[:, 2 * od + ad + 1])
+
+    def sample(self, batch_size):
+        if batch_size > 0:
+            return self.sample_index(self.make_index(batch_size))
+        return self.sample_index(torch.arange(len(self), device=self.device, dtype=torch.int64))
+
+    def collect(self):
+        return self.sample(-1)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_hip._LIB_PATH)
     for n in names:
         assert hasattr(raw, n), 'libmpe_hip.so does not export %s' % n
-    assert _hip.lib.mpe_abi_version() == _hip.ABI_VERSION == 11
+    assert _hip.lib.mpe_abi_version() == _hip.ABI_VERSION == 12
     assert _hip.lib.mpe_desc_sizeof() == ctypes.sizeof(_hip.ScenarioDesc)
     assert _hip.lib.mpe_buffers_sizeof() == ctypes.sizeof(_hip.Buffers)
 

@@ -1,10 +1,11 @@
 """The reference's training loop shape (experiments/simple_train.py:257-300) entirely on one GPU: batched env
 step -> per-agent replay rings -> MADDPG updates every 100 steps.  Prints agent-steps/s with the learner in the
 loop (run on the GPU box from the repo root):
-    python tools/train_demo.py [scenario] [num_envs] [steps] [eager|graph] [compact|full]
+    python tools/train_demo.py [scenario] [num_envs] [steps] [eager|graph] [compact|full|store]
 One episode (25 iterations) is one HIP-graph replay (marl_amd.graph.CapturedTrainSteps) and the learners' updates
 another (CapturedUpdates) unless `eager` is given.  `compact`: replay rings that store obs_tp1 once
-(marl_amd.replay_buffer.ReplayBuffer(compact=True))."""
+(marl_amd.replay_buffer.ReplayBuffer(compact=True)).  `store`: no append at all -- the actors and the env step write
+into the slots of a marl_amd.replay_buffer.StepStore (104 slots = 4 windows of 26; CapturedStoreSteps)."""
 import os
 import sys
 import time
@@ -14,9 +15,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marl_amd import make_env  # noqa: E402
-from marl_amd.graph import CapturedTrainSteps, CapturedUpdates  # noqa: E402
+from marl_amd.graph import CapturedStoreSteps, CapturedTrainSteps, CapturedUpdates  # noqa: E402
 from marl_amd.maddpg import MADDPGAgentTrainer, act_all  # noqa: E402
-from marl_amd.replay_buffer import add_all  # noqa: E402
+from marl_amd.replay_buffer import StepStore, add_all  # noqa: E402
 
 
 def main():
@@ -30,10 +31,19 @@ def main():
     trainers = [MADDPGAgentTrainer('agent_%d' % i, obs_shape_n, env.action_space, i, args, replay_size=1 << 22,
                                    seed=0, env_id0=env.world.env_id0, replay_compact=compact) for i in range(env.n)]
     eager = len(sys.argv) > 4 and sys.argv[4] == 'eager'
+    use_store = len(sys.argv) > 5 and sys.argv[5] == 'store'
     obs_n = env.reset()
     t0 = None
+    store = None
+    if use_store:
+        store = StepStore(env, 4 * (args.max_episode_len + 1))
+        for tr, view in zip(trainers, store.views()):
+            tr.replay_buffer = view
 
     def iteration(obs_n, terminal=True):
+        if store is not None:
+            act_all(trainers, obs_n, out=store.action_views())      # every agent's actor: one launch, into the slot's rows
+            return store.step()[0]                                  # the env step writes rewards and next observations there
         action_n = act_all(trainers, obs_n, out=env.action_views)   # every agent's actor: one launch, no copies
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
         add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n,
@@ -44,7 +54,10 @@ def main():
     EP = args.max_episode_len
     obs_n = iteration(obs_n)                            # the rings and the packed actor weights exist after this
     obs_n = env.reset()
-    episode = None if eager else CapturedTrainSteps(env, trainers, EP)
+    if store is not None:
+        store.align(EP + 1)
+    episode = None if eager else (CapturedStoreSteps(env, trainers, store, EP) if store is not None
+                                  else CapturedTrainSteps(env, trainers, EP))
     updates = None
     for t in range(EP, steps + 100 + 1, EP):
         if t == 100 + EP:                               # 100 warm-up steps, incl. the first update
@@ -73,7 +86,7 @@ def main():
     dt = time.perf_counter() - t0
     print('%s: %d envs x %d steps with %d learners in the loop (%s, %s replay records): %.3f ms/step, %.3e agent-steps/s'
           % (scenario, B, steps, env.n, 'eager' if eager else 'one graph replay per episode',
-             'compact' if compact else 'full', 1e3 * dt / steps,
+             'no append: step store' if use_store else ('compact' if compact else 'full'), 1e3 * dt / steps,
              B * env.n * steps / dt))
 
 
