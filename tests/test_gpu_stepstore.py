@@ -211,3 +211,39 @@ def test_captured_store_steps_refuse_a_misaligned_store():
     assert store.align(5) == 5 and len(store.views()[0]) == 256    # the eager step's transition (slot 0) is still there
     cap.replay()
     assert len(store.views()[0]) == 5 * 256
+
+
+def test_a_recorded_gather_follows_the_store_as_it_grows():
+    """marl_amd.graph.CapturedUpdates records the learners' sample_index calls in a HIP graph, which bakes the kernel
+    arguments: the number of stored steps is therefore read from device memory (behind the slot table), and a replay
+    after the store has grown -- and wrapped -- gathers what an eager call gathers."""
+    from marl_amd import make_env
+    from marl_amd.replay_buffer import StepStore
+    B = 384
+    env = make_env('simple_tag', num_envs=B, dtype=torch.float32, seed=1)
+    env.reset()
+    store = StepStore(env, 6)
+    view = store.views()[1]
+    g = torch.Generator(device='cuda').manual_seed(5)
+
+    def steps(k):
+        for _ in range(k):
+            for v in store.action_views():
+                v.copy_(torch.rand(v.shape, generator=g, device='cuda'))
+            store.step()
+    steps(2)
+    idx = torch.randint(0, len(view), (300,), generator=g, device='cuda')
+    view.check_index = False                                 # (the range check reads the indices back on the host)
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        rec = view.sample_index(idx)
+    for k in (0, 2, 1, 4):                                   # 2, 4, 5 stored steps, then a wrapped ring of 5
+        steps(k)
+        n = len(view)                                        # (uploads the slot table and the count, like make_index)
+        assert n == min(2 + sum((0, 2, 1, 4)[:(0, 2, 1, 4).index(k) + 1]), 5) * B
+        idx.copy_(torch.randint(0, n, (300,), generator=g, device='cuda'))
+        idx[0] = n - 1
+        graph.replay()
+        for x, y in zip(rec, view.sample_index(idx.clone())):
+            assert torch.equal(x, y)
