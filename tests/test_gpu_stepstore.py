@@ -113,11 +113,15 @@ def test_step_store_refuses_what_it_cannot_do():
     torch.cuda.synchronize()
 
 
-def _train_setup(B, seed=0):
+def _train_setup(B, seed=0, u_noise=None):
     import types
     from marl_amd import make_env
     from marl_amd.maddpg import MADDPGAgentTrainer
     env = make_env('simple_tag', num_envs=B, dtype=torch.float32, seed=seed)
+    if u_noise:                                              # drawn inside the step kernels, keyed by the step counter
+        for a in env.world.agents:
+            a.u_noise = u_noise
+        env.world.invalidate_descriptor()
     args = types.SimpleNamespace(lr=1e-2, gamma=0.95, batch_size=256, num_units=64, max_episode_len=25)
     obs_shape_n = [env.observation_space[i].shape for i in range(env.n)]
     torch.manual_seed(123)                                   # identical initial networks in every copy
@@ -126,13 +130,13 @@ def _train_setup(B, seed=0):
     return env, trainers
 
 
-def _train_run(B, K, mode, episodes=4):
+def _train_run(B, K, mode, episodes=4, u_noise=None):
     """mode 'ring': the classic loop (act -> step -> add_all into full-record rings); 'store': act -> StepStore.step;
     'graph': the same as one HIP-graph replay per episode.  A weight update after the second episode."""
     from marl_amd.graph import CapturedStoreSteps
     from marl_amd.maddpg import act_all
     from marl_amd.replay_buffer import StepStore, add_all
-    env, trainers = _train_setup(B)
+    env, trainers = _train_setup(B, u_noise=u_noise)
     obs_n = env.reset()
     store = cap = None
     if mode != 'ring':
@@ -171,16 +175,17 @@ def _train_run(B, K, mode, episodes=4):
     return env, trainers, store
 
 
-@pytest.mark.parametrize('K', [4, 7])
-def test_store_loops_hold_what_the_ring_loop_holds(K):
+@pytest.mark.parametrize('K,u_noise', [(4, None), (7, None), (5, 0.3)])
+def test_store_loops_hold_what_the_ring_loop_holds(K, u_noise):
     """The reference's loop shape with (a) full-record rings and one append launch per step, (b) a StepStore, (c) the
     StepStore loop as one HIP-graph replay per episode (marl_amd.graph.CapturedStoreSteps; three windows of K + 1 slots,
     the fourth episode reuses the first window's graph): the same actions, states and stored transitions, bit for bit,
-    with a learner update in between (the packed actor weights are refilled in place)."""
+    with a learner update in between (the packed actor weights are refilled in place); also with u_noise drawn in the
+    step kernels (the recorded launches take the moving part of the noise step counter from device memory)."""
     B, episodes = 512, 4
-    ring = _train_run(B, K, 'ring', episodes)
+    ring = _train_run(B, K, 'ring', episodes, u_noise)
     for mode in ('store', 'graph'):
-        env, trainers, store = _train_run(B, K, mode, episodes)
+        env, trainers, store = _train_run(B, K, mode, episodes, u_noise)
         assert torch.equal(env.world.pos, ring[0].world.pos) and torch.equal(env.world.vel, ring[0].world.vel)
         assert [tr._act_calls for tr in trainers] == [tr._act_calls for tr in ring[1]]
         L = len(trainers[0].replay_buffer) // B
