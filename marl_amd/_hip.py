@@ -34,7 +34,7 @@ FLAG_SILENT_COMM_ZERO = 8   # silent agents' comm rows already hold zeros: the s
 FLAG_DEVICE_NOISE = 16      # u_noise / c_noise normals the caller does not supply are drawn inside the step kernels
 SPLIT_MAX_ENVS = 32768
 HIER_SPLIT_MAX_ENVS = 65536
-ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA = 0, 1, 2
+ACTOR_AUTO, ACTOR_VALU, ACTOR_MFMA, ACTOR_MFMA_F16 = 0, 1, 2, 3
 
 # MARL_AMD_LIB: alternative build of the same library (kernel tuning / ablation builds only)
 _LIB_PATH = os.environ.get('MARL_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),

@@ -235,8 +235,48 @@ __device__ __forceinline__ f32x16 mfma_bf16x6(const Bf16x3 &a, const Bf16x3 &b, 
   return mfma_bf16(a.hi, b.hi, c);
 }
 
+// ---- MPE_ACTOR_MFMA_F16: the same layers from TWO f16 pieces per operand and three partial products ----------------
+// x = p1 + p2 with p1 = x truncated to f16 (11 significant bits) and p2 = (x - p1) truncated to f16: the subtraction is
+// exact, the pieces carry 22 bits, and x w = p1 q1 + p1 q2 + p2 q1 (+ terms below 2^-22 |x w|, dropped).  Each partial
+// product is exact in the f32 accumulator.  3.0 vector instructions per split value instead of 5.5 and 3 MFMAs per
+// product instead of 6 -- the loop is bound by vector issue -- at ~4e-7 relative accuracy instead
+// of f32's 6e-8, for operands inside f16's range: |value| < 65 504 (beyond it a piece saturates: wrong, finite), and a
+// second piece below 2^-14 = 6.1e-5 is a subnormal f16 with 2^-24 = 6e-8 ABSOLUTE resolution.  Opt-in for that reason.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Bf16x3 split_f16x2(const float (&x)[8]) {
+  Bf16x3 o;  // hi = p1, mid = p2, lo unused
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2v p1 = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]));
+    const float r0 = x[2 * i] - (float)p1[0], r1 = x[2 * i + 1] - (float)p1[1];
+    o.hi[i] = __builtin_bit_cast(uint32_t, p1);
+    o.mid[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    o.lo[i] = 0u;
+  }
+  return o;
+}
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_f16x3(const Bf16x3 &a, const Bf16x3 &b, f32x16 c) {
+  c = mfma_f16(a.mid, b.hi, c);
+  c = mfma_f16(a.hi, b.mid, c);
+  return mfma_f16(a.hi, b.hi, c);
+}
+template <bool F16>
+__device__ __forceinline__ Bf16x3 split_pieces(const float (&x)[8]) {
+  if constexpr (F16) return split_f16x2(x);
+  else return split_bf16x3(x);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_pieces(const Bf16x3 &a, const Bf16x3 &b, f32x16 c) {
+  if constexpr (F16) return mfma_f16x3(a, b, c);
+  else return mfma_bf16x6(a, b, c);
+}
+
 // A fragment of a [K][ncols] row-major weight matrix for output column `col` (< 0: a zero column): slot j takes row k_of(j)
-template <typename KOf>
+template <bool F16, typename KOf>
 __device__ __forceinline__ Bf16x3 weight_fragment(const float *__restrict__ W, int K, int ncols, int col, KOf k_of) {
   float w[8];
 #pragma unroll
@@ -244,14 +284,14 @@ __device__ __forceinline__ Bf16x3 weight_fragment(const float *__restrict__ W, i
     const int k = k_of(j);
     w[j] = (col >= 0 && k < K) ? W[(int64_t)k * ncols + col] : 0.0f;
   }
-  return split_bf16x3(w);
+  return split_pieces<F16>(w);
 }
 
 constexpr int kActorLdsInputs = 64;  // W1 rows kept pre-split in LDS; inputs beyond that are split per tile
 
 // O: logits rows evaluated in the epilogue, 8 or 16.  NKB: k-blocks of 16 observation rows, 1..3 compiled in (the tile
 // loop is then one straight block: next tile's rows fetched ahead, LDS reads scheduled across the MFMAs), 0 = any width.
-template <int O, int NKB>
+template <int O, int NKB, bool F16 = false>
 __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_obs, int64_t ld_act, const ActorJobs jobs,
                                                          uint32_t counter, uint64_t env_id0, int tiles_per_wave) {
   constexpr int H = kActorHidden, OP = kActorMaxOut;
@@ -280,20 +320,20 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
   for (int f = wave; f < 2 * NKB1; f += 4) {  // W1 fragments (mt = f & 1, kb = f >> 1) of the first 64 inputs
     const int kb = f >> 1;
     if (kb < nkb1) {
-      const Bf16x3 a = weight_fragment(W1, in_dim, H, 32 * (f & 1) + n, k_in(kb));
+      const Bf16x3 a = weight_fragment<F16>(W1, in_dim, H, 32 * (f & 1) + n, k_in(kb));
       sW1[3 * f + 0][lane] = a.hi;
       sW1[3 * f + 1][lane] = a.mid;
       sW1[3 * f + 2][lane] = a.lo;
     }
   }
   {  // W3 fragment of k-block `wave`
-    const Bf16x3 a = weight_fragment(W3, H, OP, n < OP ? n : -1, k_acc(wave));
+    const Bf16x3 a = weight_fragment<F16>(W3, H, OP, n < OP ? n : -1, k_acc(wave));
     sW3[3 * wave + 0][lane] = a.hi;
     sW3[3 * wave + 1][lane] = a.mid;
     sW3[3 * wave + 2][lane] = a.lo;
   }
   for (int f = wave; f < 8; f += 4) {  // W2 fragments (mt = f & 1, kb = f >> 1)
-    const Bf16x3 a = weight_fragment(W2, H, H, 32 * (f & 1) + n, k_acc(f >> 1));
+    const Bf16x3 a = weight_fragment<F16>(W2, H, H, 32 * (f & 1) + n, k_acc(f >> 1));
     sW2[3 * f + 0][lane] = a.hi;
     sW2[3 * f + 1][lane] = a.mid;
     sW2[3 * f + 2][lane] = a.lo;
@@ -362,7 +402,7 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
       }
     }
     auto layer1_block = [&](int kb, const float (&x)[8]) {
-      const Bf16x3 b = split_bf16x3(x);
+      const Bf16x3 b = split_pieces<F16>(x);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         Bf16x3 a;
@@ -370,11 +410,11 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
           const int f = 2 * kb + mt;
           a.hi = sW1[3 * f + 0][lane];
           a.mid = sW1[3 * f + 1][lane];
-          a.lo = sW1[3 * f + 2][lane];
+          if constexpr (!F16) a.lo = sW1[3 * f + 2][lane];
         } else {
-          a = weight_fragment(W1, in_dim, H, 32 * mt + n, k_in(kb));
+          a = weight_fragment<F16>(W1, in_dim, H, 32 * mt + n, k_in(kb));
         }
-        acc1[mt] = mfma_bf16x6(a, b, acc1[mt]);
+        acc1[mt] = mfma_pieces<F16>(a, b, acc1[mt]);
       }
     };
 #pragma unroll
@@ -401,15 +441,15 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = relu1(acc1[kb >> 1][8 * (kb & 1) + j]);
-      const Bf16x3 b = split_bf16x3(x);
+      const Bf16x3 b = split_pieces<F16>(x);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int f = 2 * kb + mt;
         Bf16x3 a;
         a.hi = sW2[3 * f + 0][lane];
         a.mid = sW2[3 * f + 1][lane];
-        a.lo = sW2[3 * f + 2][lane];
-        acc2[mt] = mfma_bf16x6(a, b, acc2[mt]);
+        if constexpr (!F16) a.lo = sW2[3 * f + 2][lane];
+        acc2[mt] = mfma_pieces<F16>(a, b, acc2[mt]);
       }
     }
     // ---- layer 3: one tile of logits (rows >= 16 are padding)
@@ -424,12 +464,12 @@ __global__ __launch_bounds__(256) void actor_mfma_kernel(int64_t B, int64_t ld_o
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = relu1(acc2[kb >> 1][8 * (kb & 1) + j]);
-      const Bf16x3 b = split_bf16x3(x);
+      const Bf16x3 b = split_pieces<F16>(x);
       Bf16x3 a;
       a.hi = sW3[3 * kb + 0][lane];
       a.mid = sW3[3 * kb + 1][lane];
-      a.lo = sW3[3 * kb + 2][lane];
-      acc3 = mfma_bf16x6(a, b, acc3);
+      if constexpr (!F16) a.lo = sW3[3 * kb + 2][lane];
+      acc3 = mfma_pieces<F16>(a, b, acc3);
     }
     // ---- Gumbel-softmax per sub-space; this lane holds logits rows mfma_row(r, h), r < O / 2, of env n
     constexpr int R = O / 2;

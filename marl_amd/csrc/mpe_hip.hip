@@ -1406,7 +1406,7 @@ extern "C" int mpe_actor_forward_multi_ctr_f32(int n_jobs, const mpe_actor_job *
                                                uint64_t env_id0, int kernel, void *stream) {
   if (!jobs) return MPE_ERR_NULL;
   if (misaligned<uint32_t>(counter_dev)) return MPE_ERR_ALIGN;
-  if (n_jobs < 1 || kernel < MPE_ACTOR_AUTO || kernel > MPE_ACTOR_MFMA) return MPE_ERR_ARG;
+  if (n_jobs < 1 || kernel < MPE_ACTOR_AUTO || kernel > MPE_ACTOR_MFMA_F16) return MPE_ERR_ARG;
   if (B < 1 || ld_obs < B || ld_act < B) return MPE_ERR_BATCH;
   for (int i = 0; i < n_jobs; ++i) {
     const int rc = actor_job_check(&jobs[i]);
@@ -1440,11 +1440,15 @@ extern "C" int mpe_actor_forward_multi_ctr_f32(int n_jobs, const mpe_actor_job *
         if ((tab.j[i].in_dim + 15) / 16 != nkb) nkb = 0;
       if (nkb > 3 || (int64_t)48 * ld_obs >= ((int64_t)1 << 30)) nkb = 0;  // 32-bit row offsets inside the kernel
       using Kern = void (*)(int64_t, int64_t, int64_t, const ActorJobs, uint32_t, uint64_t, int);
-      static const Kern kerns[2][4] = {
-          {actor_mfma_kernel<8, 0>, actor_mfma_kernel<8, 1>, actor_mfma_kernel<8, 2>, actor_mfma_kernel<8, 3>},
-          {actor_mfma_kernel<16, 0>, actor_mfma_kernel<16, 1>, actor_mfma_kernel<16, 2>, actor_mfma_kernel<16, 3>}};
-      hipLaunchKernelGGL(kerns[wide][nkb], grid, block, 0, (hipStream_t)stream, B, ld_obs, ld_act, tab, call_counter,
-                         env_id0, tpw);
+      static const Kern kerns[2][2][4] = {
+          {{actor_mfma_kernel<8, 0>, actor_mfma_kernel<8, 1>, actor_mfma_kernel<8, 2>, actor_mfma_kernel<8, 3>},
+           {actor_mfma_kernel<16, 0>, actor_mfma_kernel<16, 1>, actor_mfma_kernel<16, 2>, actor_mfma_kernel<16, 3>}},
+          {{actor_mfma_kernel<8, 0, true>, actor_mfma_kernel<8, 1, true>, actor_mfma_kernel<8, 2, true>,
+            actor_mfma_kernel<8, 3, true>},
+           {actor_mfma_kernel<16, 0, true>, actor_mfma_kernel<16, 1, true>, actor_mfma_kernel<16, 2, true>,
+            actor_mfma_kernel<16, 3, true>}}};
+      hipLaunchKernelGGL(kerns[kernel == MPE_ACTOR_MFMA_F16][wide][nkb], grid, block, 0, (hipStream_t)stream, B, ld_obs,
+                         ld_act, tab, call_counter, env_id0, tpw);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

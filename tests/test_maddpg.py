@@ -145,7 +145,7 @@ def test_update_follows_the_reference_arithmetic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kernel', [1, 2], ids=['valu', 'mfma'])
+@pytest.mark.parametrize('kernel', [1, 2, 3], ids=['valu', 'mfma', 'mfma_f16'])
 @pytest.mark.parametrize('in_dim,sizes', [(16, [5]), (34, [5, 4]), (20, [5, 7]), (3, [3]), (11, [5, 10]), (244, [5])])
 def test_fused_actor_kernel_matches_torch(in_dim, sizes, kernel):
     """mpe_actor_forward_f32 against the plain PyTorch fp32 forward + Gumbel-softmax with the same uniforms:
@@ -168,7 +168,9 @@ def test_fused_actor_kernel_matches_torch(in_dim, sizes, kernel):
     with torch.no_grad():
         noisy = net(obs) - torch.log(-torch.log(u))
         want = torch.cat([torch.softmax(p, -1) for p in torch.split(noisy, sizes, -1)], -1)
-    assert float((got - want).abs().max()) <= 1e-5
+    err = float((got - want).abs().max())
+    print('actor kernel %d, %d inputs: max |err| vs torch f32 = %.2e' % (kernel, in_dim, err))
+    assert err <= 1e-5              # (the opt-in f16 form, kernel 3, carries 22 significant bits per operand: same bar)
     own = actor_forward(packed, obs, sizes, seed=7, call_counter=1)       # the kernel's own Philox draw
     again = actor_forward(packed, obs, sizes, seed=7, call_counter=1)
     other = actor_forward(packed, obs, sizes, seed=7, call_counter=2)

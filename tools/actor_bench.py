@@ -18,7 +18,7 @@ def main():
         net = mlp_model(in_dim, sum(sizes)).cuda()
         packed = pack_actor(net)
         obs = torch.randn(in_dim, ld, device='cuda')[:, :B].t()
-        for kernel, name in ((1, 'vector FMA'), (2, 'bf16x6 MFMA')):
+        for kernel, name in ((1, 'vector FMA'), (2, 'bf16x6 MFMA'), (3, 'f16x3 MFMA ')):
             for c in range(3):
                 actor_forward(packed, obs, sizes, seed=1, call_counter=c, kernel=kernel)
             torch.cuda.synchronize()

@@ -1,11 +1,12 @@
 """The reference's training loop shape (experiments/simple_train.py:257-300) entirely on one GPU: batched env
 step -> per-agent replay rings -> MADDPG updates every 100 steps.  Prints agent-steps/s with the learner in the
 loop (run on the GPU box from the repo root):
-    python tools/train_demo.py [scenario] [num_envs] [steps] [eager|graph] [compact|full|store]
+    python tools/train_demo.py [scenario] [num_envs] [steps] [eager|graph] [compact|full|store] [f16actor]
 One episode (25 iterations) is one HIP-graph replay (marl_amd.graph.CapturedTrainSteps) and the learners' updates
 another (CapturedUpdates) unless `eager` is given.  `compact`: replay rings that store obs_tp1 once
 (marl_amd.replay_buffer.ReplayBuffer(compact=True)).  `store`: no append at all -- the actors and the env step write
-into the slots of a marl_amd.replay_buffer.StepStore (104 slots = 4 windows of 26; CapturedStoreSteps)."""
+into the slots of a marl_amd.replay_buffer.StepStore (104 slots = 4 windows of 26; CapturedStoreSteps).  `f16actor`: the
+opt-in actor kernel on two f16 pieces per operand (MPE_ACTOR_MFMA_F16: ~1e-6 instead of ~4e-7 against PyTorch f32)."""
 import os
 import sys
 import time
@@ -32,6 +33,7 @@ def main():
                                    seed=0, env_id0=env.world.env_id0, replay_compact=compact) for i in range(env.n)]
     eager = len(sys.argv) > 4 and sys.argv[4] == 'eager'
     use_store = len(sys.argv) > 5 and sys.argv[5] == 'store'
+    actor_kernel = 3 if 'f16actor' in sys.argv[6:] else 0
     obs_n = env.reset()
     t0 = None
     store = None
@@ -42,9 +44,9 @@ def main():
 
     def iteration(obs_n, terminal=True):
         if store is not None:
-            act_all(trainers, obs_n, out=store.action_views())      # every agent's actor: one launch, into the slot's rows
+            act_all(trainers, obs_n, out=store.action_views(), kernel=actor_kernel)   # every agent's actor: one launch, into the slot's rows
             return store.step()[0]                                  # the env step writes rewards and next observations there
-        action_n = act_all(trainers, obs_n, out=env.action_views)   # every agent's actor: one launch, no copies
+        action_n = act_all(trainers, obs_n, out=env.action_views, kernel=actor_kernel)   # every agent's actor: one launch, no copies
         new_obs_n, rew_n, done_n, info_n = env.step(action_n)
         add_all([tr.replay_buffer for tr in trainers], obs_n, action_n, rew_n, new_obs_n, done_n,
                 terminal=terminal)                                  # every agent's append: one launch
@@ -56,8 +58,8 @@ def main():
     obs_n = env.reset()
     if store is not None:
         store.align(EP + 1)
-    episode = None if eager else (CapturedStoreSteps(env, trainers, store, EP) if store is not None
-                                  else CapturedTrainSteps(env, trainers, EP))
+    episode = None if eager else (CapturedStoreSteps(env, trainers, store, EP, kernel=actor_kernel) if store is not None
+                                  else CapturedTrainSteps(env, trainers, EP, kernel=actor_kernel))
     updates = None
     for t in range(EP, steps + 100 + 1, EP):
         if t == 100 + EP:                               # 100 warm-up steps, incl. the first update
@@ -84,9 +86,9 @@ def main():
             print('step %5d  q_loss %.4f  p_loss %.4f  mean reward %.3f' % (t, float(out[0]), float(out[1]), float(out[3])))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print('%s: %d envs x %d steps with %d learners in the loop (%s, %s replay records): %.3f ms/step, %.3e agent-steps/s'
+    print('%s: %d envs x %d steps with %d learners in the loop (%s, replay: %s): %.3f ms/step, %.3e agent-steps/s'
           % (scenario, B, steps, env.n, 'eager' if eager else 'one graph replay per episode',
-             'no append: step store' if use_store else ('compact' if compact else 'full'), 1e3 * dt / steps,
+             ('step store (no append)' if use_store else ('compact records' if compact else 'full records')) + ('; f16 actor kernel' if actor_kernel else ''), 1e3 * dt / steps,
              B * env.n * steps / dt))
 
 
