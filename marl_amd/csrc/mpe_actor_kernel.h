@@ -238,7 +238,7 @@ __device__ __forceinline__ f32x16 mfma_bf16x6(const Bf16x3 &a, const Bf16x3 &b, 
 // ---- MPE_ACTOR_MFMA_F16: the same layers from TWO f16 pieces per operand and three partial products ----------------
 // x = p1 + p2 with p1 = x truncated to f16 (11 significant bits) and p2 = (x - p1) truncated to f16: the subtraction is
 // exact, the pieces carry 22 bits, and x w = p1 q1 + p1 q2 + p2 q1 (+ terms below 2^-22 |x w|, dropped).  Each partial
-// product is exact in the f32 accumulator.  3.0 vector instructions per split value instead of 5.5 and 3 MFMAs per
+// product is exact in the f32 accumulator.  2.0 vector instructions per split value instead of 5.5 and 3 MFMAs per
 // product instead of 6 -- the loop is bound by vector issue -- at ~4e-7 relative accuracy instead
 // of f32's 6e-8, for operands inside f16's range: |value| < 65 504 (beyond it a piece saturates: wrong, finite), and a
 // second piece below 2^-14 = 6.1e-5 is a subnormal f16 with 2^-24 = 6e-8 ABSOLUTE resolution.  Opt-in for that reason.
@@ -249,8 +249,13 @@ __device__ __forceinline__ Bf16x3 split_f16x2(const float (&x)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const f16x2v p1 = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]));
-    const float r0 = x[2 * i] - (float)p1[0], r1 = x[2 * i + 1] - (float)p1[1];
-    o.hi[i] = __builtin_bit_cast(uint32_t, p1);
+    // x - p1 as one mixed-precision FMA that reads the f16 half in place (v_fma_mix_f32: p1.half * -1.0 + x, exact): no
+    // conversion instruction (written as C the compiler folds it back into v_cvt_f32_f16 + v_sub_f32)
+    const uint32_t pw = __builtin_bit_cast(uint32_t, p1);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pw), "v"(x[2 * i]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pw), "v"(x[2 * i + 1]));
+    o.hi[i] = pw;
     o.mid[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     o.lo[i] = 0u;
   }
