@@ -515,7 +515,7 @@ typedef struct mpe_actor_job {
                             products per product: the error of an f32 dot product; 32 envs per tile on the lane axis */
 #define MPE_ACTOR_MFMA_F16 3 /* opt-in: the same on TWO f16 pieces per operand (22 significant bits) and three partial products,
                                 v_mfma_f32_32x32x16_f16: ~4e-7 relative instead of f32's 6e-8, operands must lie inside f16's
-                                range (|value| < 65 504; pieces below 6.1e-5 resolve 6e-8 absolute); 1.5x the launch rate */
+                                range (|value| < 65 504; pieces below 6.1e-5 resolve 6e-8 absolute); 1.3x the launch rate */
 int mpe_actor_forward_multi_f32(int n_jobs, const mpe_actor_job *jobs, int64_t B, int64_t ld_obs, int64_t ld_act,
                                 uint32_t call_counter, uint64_t env_id0, int kernel, void *stream);
 /* The same with a device word added to call_counter (counter_dev may be NULL = 0): for acting steps recorded in a HIP
