@@ -307,3 +307,30 @@ def test_act_all_and_add_all_equal_the_per_agent_calls(scenario):
     a_in = act_all(trainers(), obs_n, out=env.action_views)
     for x, y, v in zip(a_in, a_ref, env.action_views):
         assert x.data_ptr() == v.data_ptr() and torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_f16_actor_kernel_at_the_edges_of_its_range():
+    """MPE_ACTOR_MFMA_F16 (opt-in) splits every operand into two f16 pieces: observations of 1e-6 (pieces in f16's
+    subnormal range: 6e-8 absolute resolution) still meet the 1e-5 bar against PyTorch f32; observations beyond +-65 504
+    saturate -- the documented price -- but stay finite and normalised (no inf - inf in the softmax)."""
+    from marl_amd import maddpg
+    from marl_amd.maddpg import pack_actor
+    torch.manual_seed(3)
+    B, ld, in_dim, sizes = 4096 + 5, 4352, 16, [5]
+    net = mlp_model(in_dim, 5).cuda()
+    packed = pack_actor(net)
+    u = torch.rand(B, 5, device='cuda').clamp_(1e-6, 1 - 1e-6)
+    for scale in (1e-6, 1e-3, 30.0):
+        obs = (torch.randn(in_dim, ld, device='cuda') * scale)[:, :B].t()
+        got = maddpg.actor_forward(packed, obs, sizes, u=u, kernel=3)
+        with torch.no_grad():
+            want = torch.softmax(net(obs) - torch.log(-torch.log(u)), -1)
+        assert float((got - want).abs().max()) <= 1e-5, scale
+    huge = (torch.randn(in_dim, ld, device='cuda') * 1e6)[:, :B].t()
+    got = maddpg.actor_forward(packed, huge, sizes, u=u, kernel=3)
+    assert torch.isfinite(got).all() and torch.allclose(got.sum(1), torch.ones(B, device='cuda'), atol=1e-5)
+    ref = maddpg.actor_forward(packed, huge, sizes, u=u, kernel=2)          # the default kernel has f32's range
+    with torch.no_grad():
+        want = torch.softmax(net(huge) - torch.log(-torch.log(u)), -1)
+    assert float((ref - want).abs().max()) <= 1e-4 and float((got - want).abs().max()) > 1e-2
