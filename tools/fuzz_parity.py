@@ -404,7 +404,7 @@ def main():
     n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     mode = sys.argv[3:]
-    bad, refused, kinds = run(n_worlds, seed, stock_only=('moving' if 'moving' in mode else 'stock' in mode), progress=500, grid='grid' in mode)
+    bad, refused, kinds = run(n_worlds, seed, stock_only=('moving' if 'moving' in mode else 'stock' in mode), progress=500 if int(os.environ.get('FUZZ_ENVS', 257)) <= 1000 else 50, grid='grid' in mode)
     print('worlds %d (refused by mpe_desc_check: %d), by kind %s, mismatching (world, kernel) runs: %d'
           % (n_worlds, refused, kinds, bad))
     sys.exit(1 if bad else 0)
